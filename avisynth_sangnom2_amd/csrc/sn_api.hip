@@ -1,0 +1,415 @@
+// sn_api.hip -- the C ABI of libsangnom_hip.so (include/sangnom_hip.h): context life cycle,
+// argument validation, and per-frame dispatch of the HIP kernels.
+//
+// Mirrors, on the host side, the reference's constructor and GetFrame
+// (/root/reference/src/SangNom2.cpp:275-330 and :332-397); all pixel work happens in the kernels
+// of sn_pool_kernels.hip / sn_fused_u8.hip.  There is no CPU fallback in this library.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "sn_internal.h"
+
+namespace sn {
+
+struct Context {
+    sn_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    int out_height = 0;  // vi.height after dh, SangNom2.cpp:284-285
+    int stride_e = 0;    // SangNom2.cpp:287
+    int bh = 0;          // SangNom2.cpp:288
+    float aaf[3] = {0, 0, 0};
+    bool process[3] = {true, true, true};
+    bool history_free = false;
+    bool use_fused = false;
+
+    PoolArgs pool{};
+    int slots = 1;
+
+    // staging for sn_process_host
+    uint8_t* stage_src[3] = {nullptr, nullptr, nullptr};
+    uint8_t* stage_dst[3] = {nullptr, nullptr, nullptr};
+    int stage_src_pitch[3] = {0, 0, 0};
+    int stage_dst_pitch[3] = {0, 0, 0};
+
+    FusedPlan* fused = nullptr;
+
+    int64_t frames = 0, fused_frames = 0;
+    std::string err;
+
+    int plane_w(int p) const { return p == 0 ? cfg.width : cfg.width >> cfg.sub_w; }
+    int plane_h_in(int p) const { return p == 0 ? cfg.height : cfg.height >> cfg.sub_h; }
+    int plane_h_out(int p) const { return p == 0 ? out_height : out_height >> cfg.sub_h; }
+    int nplanes() const { return cfg.num_planes < 3 ? cfg.num_planes : 3; }
+    double threshold(int p) const
+    {
+        switch (cfg.bytes_per_sample) {
+        case 1: return (double)(uint8_t)aaf[p];   // float -> T at the finalizePlane_c call,
+        case 2: return (double)(uint16_t)aaf[p];  // SangNom2.cpp:272
+        default: return (double)aaf[p];
+        }
+    }
+};
+
+static thread_local std::string g_last_error;
+
+static int fail(Context* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_last_error = buf;
+    return code;
+}
+
+#define SN_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, SN_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));       \
+    } while (0)
+
+// Create_SangNom2, SangNom2.cpp:407-422 (RGB / non-planar clips cannot be described by sn_config;
+// `opt` does not exist on this path).
+static const char* validate_text(const sn_config& c)
+{
+    const bool is420 = c.num_planes >= 3 && c.sub_w == 1 && c.sub_h == 1;
+    if (c.height % 2 != 0) return "SangNom2: height must be even.";
+    if (is420 && c.height % 4) return "SangNom2: height must be mod4.";
+    if (c.order < 0 || c.order > 2) return "SangNom2: order must be between 0..2.";
+    if (c.aa < 0 || c.aa > 128) return "SangNom2: aa must be between 0..128.";
+    if (c.aac < 0 || c.aac > 128) return "SangNom2: aac must be between 0..128.";
+    return nullptr;
+}
+
+static const char* structural_text(const sn_config& c)
+{
+    if (c.struct_size != (int32_t)sizeof(sn_config)) return "sn_config.struct_size mismatch";
+    if (c.width <= 0 || c.height <= 0) return "width and height must be positive";
+    if (c.bytes_per_sample != 1 && c.bytes_per_sample != 2 && c.bytes_per_sample != 4)
+        return "bytes_per_sample must be 1, 2 or 4";
+    if (c.bytes_per_sample == 1 && c.bits_per_sample != 8) return "8-bit samples need bits_per_sample 8";
+    if (c.bytes_per_sample == 2 && (c.bits_per_sample < 9 || c.bits_per_sample > 16))
+        return "16-bit containers need bits_per_sample 9..16";
+    if (c.bytes_per_sample == 4 && c.bits_per_sample != 32) return "float samples need bits_per_sample 32";
+    if (c.num_planes != 1 && c.num_planes != 3) return "num_planes must be 1 or 3";
+    if (c.sub_w < 0 || c.sub_w > 2 || c.sub_h < 0 || c.sub_h > 2) return "sub_w / sub_h must be 0..2";
+    if (c.num_planes == 3 && ((c.width & ((1 << c.sub_w) - 1)) || (c.height & ((1 << c.sub_h) - 1))))
+        return "luma size must be a multiple of the chroma subsampling";
+    if (c.max_batch < 0) return "max_batch must be >= 0";
+    if (c.mode < SN_MODE_AUTO || c.mode > SN_MODE_FUSED) return "mode must be SN_MODE_AUTO/POOL/FUSED";
+    return nullptr;
+}
+
+// A frame's result cannot depend on earlier frames iff every pool cell that a pass reads was
+// written earlier in the same frame or is never written at all (rows 0 and bh).  See SURVEY.md
+// section 0.7 / 7-H2: needs stride_e == width, and for subsampled chroma a luma pass before it.
+static bool compute_history_free(const Context& c)
+{
+    if (c.stride_e != c.cfg.width) return false;
+    if (c.nplanes() == 1) return true;
+    const bool luma_pass = c.cfg.dh || c.cfg.luma;
+    const bool chroma_pass = c.cfg.dh || c.cfg.chroma;
+    if (!chroma_pass) return true;
+    if (c.cfg.sub_w == 0 && c.cfg.sub_h == 0) return true;  // chroma rewrites the whole pool
+    return luma_pass;
+}
+
+}  // namespace sn
+
+using sn::Context;
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int sn_abi_version(void) { return SN_ABI_VERSION; }
+
+const char* sn_last_error(const sn_context* ctx)
+{
+    if (ctx) return reinterpret_cast<const Context*>(ctx)->err.c_str();
+    return sn::g_last_error.c_str();
+}
+
+int sn_validate(const sn_config* cfg, char* msg, size_t msg_len)
+{
+    if (!cfg) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "cfg is NULL");
+    const char* t = sn::structural_text(*cfg);
+    int rc = SN_OK;
+    if (t) rc = SN_ERR_INVALID_ARG;
+    else if ((t = sn::validate_text(*cfg)) != nullptr) rc = SN_ERR_CONFIG;
+    if (msg && msg_len) snprintf(msg, msg_len, "%s", t ? t : "");
+    if (t) sn::g_last_error = t;
+    return rc;
+}
+
+void sn_destroy(sn_context* h)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->pool.base) (void)hipFree(c->pool.base);
+    for (int p = 0; p < 3; ++p) {
+        if (c->stage_src[p]) (void)hipFree(c->stage_src[p]);
+        if (c->stage_dst[p]) (void)hipFree(c->stage_dst[p]);
+    }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(const sn_config* cfg, Context* c)
+{
+    c->cfg = *cfg;
+    if (c->cfg.max_batch < 1) c->cfg.max_batch = 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return sn::fail(c, SN_ERR_NO_DEVICE, "no HIP device available (libsangnom_hip has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return sn::fail(c, SN_ERR_NO_DEVICE, "HIP device %d out of range (0..%d)", cfg->device, ndev - 1);
+    c->device = cfg->device;
+    SN_HIP(c, hipSetDevice(c->device));
+
+    // constructor arithmetic, SangNom2.cpp:276-288
+    const int aa[3] = {cfg->aa, cfg->aac, cfg->aac};
+    for (int i = 0; i < c->nplanes(); ++i)
+        c->aaf[i] = cfg->bytes_per_sample < 4
+                        ? (aa[i] * 21.0f / 16.0f) * (float)(1 << (cfg->bits_per_sample - 8))
+                        : (aa[i] * 21.0f / 16.0f) / 256.0f;
+    c->process[0] = cfg->luma != 0;
+    c->process[1] = c->process[2] = cfg->chroma != 0;
+    c->out_height = cfg->dh ? cfg->height * 2 : cfg->height;
+    c->stride_e = (cfg->width + 31) & ~31;
+    c->bh = (c->out_height + 1) >> 1;
+    if (c->stride_e > 8192)
+        return sn::fail(c, SN_ERR_UNSUPPORTED, "width %d exceeds the supported maximum of 8192", cfg->width);
+    if (c->out_height / 2 > 65535)
+        return sn::fail(c, SN_ERR_UNSUPPORTED, "height %d exceeds the supported maximum", cfg->height);
+    c->history_free = sn::compute_history_free(*c);
+    c->slots = c->history_free ? c->cfg.max_batch : 1;
+
+    const bool eligible = sn::fused_eligible(c->cfg);
+    if (cfg->mode == SN_MODE_FUSED && !eligible)
+        return sn::fail(c, SN_ERR_UNSUPPORTED, "SN_MODE_FUSED requested but this configuration is not eligible");
+    c->use_fused = eligible && cfg->mode != SN_MODE_POOL;
+
+    if (cfg->stream) {
+        c->stream = reinterpret_cast<hipStream_t>(cfg->stream);
+    } else {
+        SN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+
+    // the pool: zero-filled (the convention that makes the reference's output defined)
+    c->pool.stride_e = c->stride_e;
+    c->pool.bh = c->bh;
+    c->pool.slot_bytes = (int64_t)sn::kBuffers * (c->bh + 1) * c->stride_e * cfg->bytes_per_sample;
+    c->pool.slot_bytes = (c->pool.slot_bytes + 255) & ~(int64_t)255;
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->pool.base), (size_t)c->pool.slot_bytes * c->slots));
+    SN_HIP(c, hipMemsetAsync(c->pool.base, 0, (size_t)c->pool.slot_bytes * c->slots, c->stream));
+    SN_HIP(c, hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+int sn_create(const sn_config* cfg, sn_context** out)
+{
+    if (!cfg || !out) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "cfg / out is NULL");
+    *out = nullptr;
+    char msg[256];
+    int rc = sn_validate(cfg, msg, sizeof msg);
+    if (rc != SN_OK) return rc;  // g_last_error already holds the text
+    Context* c = new (std::nothrow) Context();
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "out of host memory");
+    rc = create_impl(cfg, c);
+    if (rc != SN_OK) {
+        sn::g_last_error = c->err;
+        sn_destroy(reinterpret_cast<sn_context*>(c));
+        return rc;
+    }
+    *out = reinterpret_cast<sn_context*>(c);
+    return SN_OK;
+}
+
+// GetFrame's field choice, SangNom2.cpp:336-341.
+static int field_offset(const Context* c, int parity)
+{
+    switch (c->cfg.order) {
+    case 0: return parity ? 0 : 1;
+    case 1: return 0;
+    default: return 1;
+    }
+}
+
+static int check_planes(Context* c, const void* const src[3], const int32_t sp[3], void* const dst[3],
+                        const int32_t dp[3])
+{
+    if (!src || !sp || !dst || !dp) return sn::fail(c, SN_ERR_INVALID_ARG, "plane array is NULL");
+    for (int p = 0; p < c->nplanes(); ++p) {
+        const int rb = c->plane_w(p) * c->cfg.bytes_per_sample;
+        if (!src[p] || !dst[p]) return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pointer is NULL", p);
+        if (sp[p] < rb || dp[p] < rb)
+            return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pitch smaller than the row size %d", p, rb);
+        if (sp[p] % c->cfg.bytes_per_sample || dp[p] % c->cfg.bytes_per_sample ||
+            (uintptr_t)src[p] % c->cfg.bytes_per_sample || (uintptr_t)dst[p] % c->cfg.bytes_per_sample)
+            return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pointer/pitch not aligned to the sample size", p);
+    }
+    return SN_OK;
+}
+
+// Runs frames [f0, f0 + n) of a strided batch with one common field offset.
+static int run_group(Context* c, int n, const void* const src[3], const int64_t sfs[3], const int32_t sp[3],
+                     void* const dst[3], const int64_t dfs[3], const int32_t dp[3], int f0, int offset)
+{
+    for (int p = 0; p < c->nplanes(); ++p) {
+        sn::PlaneArgs a{};
+        a.src = static_cast<const uint8_t*>(src[p]) + (int64_t)f0 * sfs[p];
+        a.dst = static_cast<uint8_t*>(dst[p]) + (int64_t)f0 * dfs[p];
+        a.src_frame_stride = sfs[p];
+        a.dst_frame_stride = dfs[p];
+        a.src_pitch = sp[p];
+        a.dst_pitch = dp[p];
+        a.w = c->plane_w(p);
+        a.h_in = c->plane_h_in(p);
+        a.h_out = c->plane_h_out(p);
+        a.offset = offset;
+        a.dh = c->cfg.dh;
+        a.enabled = (c->cfg.dh || c->process[p]) ? 1 : 0;
+        SN_HIP(c, sn::launch_assemble(c->stream, a, c->cfg.bytes_per_sample, n));
+        if (!a.enabled) continue;
+        SN_HIP(c, sn::launch_pool_plane(c->stream, a, c->pool, c->cfg.bytes_per_sample, c->threshold(p), n, 0));
+    }
+    return SN_OK;
+}
+
+int sn_process_device_strided(sn_context* h, int32_t nframes, const void* const src[3],
+                              const int64_t sfs[3], const int32_t sp[3], void* const dst[3],
+                              const int64_t dfs[3], const int32_t dp[3], const int32_t* parity)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (nframes < 0 || nframes > c->cfg.max_batch)
+        return sn::fail(c, SN_ERR_INVALID_ARG, "nframes %d outside 0..max_batch (%d)", nframes, c->cfg.max_batch);
+    if (!sfs || !dfs) return sn::fail(c, SN_ERR_INVALID_ARG, "frame stride array is NULL");
+    int rc = check_planes(c, src, sp, dst, dp);
+    if (rc != SN_OK) return rc;
+    if (nframes == 0) return SN_OK;
+    SN_HIP(c, hipSetDevice(c->device));
+
+    // Split the batch into runs of equal field offset; history-carrying configurations run one
+    // frame at a time on pool slot 0, exactly like one reference instance.
+    int f = 0;
+    while (f < nframes) {
+        const int off = field_offset(c, parity ? parity[f] : 1);
+        int g = f + 1;
+        if (c->history_free)
+            while (g < nframes && field_offset(c, parity ? parity[g] : 1) == off) ++g;
+        rc = run_group(c, g - f, src, sfs, sp, dst, dfs, dp, f, off);
+        if (rc != SN_OK) return rc;
+        f = g;
+    }
+    c->frames += nframes;
+    return SN_OK;
+}
+
+int sn_process_device(sn_context* h, const void* const src[3], const int32_t sp[3], void* const dst[3],
+                      const int32_t dp[3], int32_t parity)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    const int64_t zero[3] = {0, 0, 0};
+    return sn_process_device_strided(h, 1, src, zero, sp, dst, zero, dp, &parity);
+}
+
+int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3], void* const dst[3],
+                    const int32_t dp[3], int32_t parity)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    int rc = check_planes(c, src, sp, dst, dp);
+    if (rc != SN_OK) return rc;
+    SN_HIP(c, hipSetDevice(c->device));
+    const int B = c->cfg.bytes_per_sample;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        if (!c->stage_src[p]) {
+            c->stage_src_pitch[p] = (c->plane_w(p) * B + 255) & ~255;
+            c->stage_dst_pitch[p] = c->stage_src_pitch[p];
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_src[p]),
+                                (size_t)c->stage_src_pitch[p] * c->plane_h_in(p)));
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_dst[p]),
+                                (size_t)c->stage_dst_pitch[p] * c->plane_h_out(p)));
+        }
+        SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p], c->stage_src_pitch[p], src[p], sp[p],
+                                   (size_t)c->plane_w(p) * B, c->plane_h_in(p), hipMemcpyHostToDevice, c->stream));
+    }
+    const void* dsrc[3] = {c->stage_src[0], c->stage_src[1], c->stage_src[2]};
+    void* ddst[3] = {c->stage_dst[0], c->stage_dst[1], c->stage_dst[2]};
+    rc = sn_process_device(h, dsrc, c->stage_src_pitch, ddst, c->stage_dst_pitch, parity);
+    if (rc != SN_OK) return rc;
+    for (int p = 0; p < c->nplanes(); ++p)
+        SN_HIP(c, hipMemcpy2DAsync(dst[p], dp[p], c->stage_dst[p], c->stage_dst_pitch[p],
+                                   (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyDeviceToHost, c->stream));
+    SN_HIP(c, hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+int sn_synchronize(sn_context* h)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    SN_HIP(c, hipSetDevice(c->device));
+    SN_HIP(c, hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+void* sn_get_stream(sn_context* h)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    return c ? reinterpret_cast<void*>(c->stream) : nullptr;
+}
+
+int sn_get_info(sn_context* h, sn_info* info)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (!info || info->struct_size != (int32_t)sizeof(sn_info))
+        return sn::fail(c, SN_ERR_INVALID_ARG, "sn_info.struct_size mismatch");
+    info->out_height = c->out_height;
+    info->pool_stride = c->stride_e;
+    info->pool_rows = c->bh + 1;
+    info->fused_eligible = sn::fused_eligible(c->cfg) ? 1 : 0;
+    info->history_free = c->history_free ? 1 : 0;
+    info->frames = c->frames;
+    info->fused_frames = c->fused_frames;
+    info->fused_tiles_rejected = 0;
+    for (int p = 0; p < 3; ++p) info->threshold[p] = p < c->nplanes() ? c->threshold(p) : 0.0;
+    return SN_OK;
+}
+
+int sn_debug_read_pool(sn_context* h, int32_t slot, void* host_dst, size_t bytes)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    const size_t need = (size_t)sn::kBuffers * (c->bh + 1) * c->stride_e * c->cfg.bytes_per_sample;
+    if (!host_dst || bytes < need || slot < 0 || slot >= c->slots)
+        return sn::fail(c, SN_ERR_INVALID_ARG, "sn_debug_read_pool: bad slot or buffer too small (%zu needed)", need);
+    SN_HIP(c, hipSetDevice(c->device));
+    SN_HIP(c, hipStreamSynchronize(c->stream));
+    SN_HIP(c, hipMemcpy(host_dst, c->pool.base + (int64_t)slot * c->pool.slot_bytes, need, hipMemcpyDeviceToHost));
+    return SN_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop
+
+namespace sn {
+// Placeholder until sn_fused_u8.hip lands: nothing is eligible, everything takes the pool path.
+bool fused_eligible(const sn_config&) { return false; }
+}  // namespace sn

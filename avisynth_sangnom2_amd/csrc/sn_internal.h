@@ -1,0 +1,49 @@
+// sn_internal.h -- shared declarations of libsangnom_hip.so (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "sangnom_hip.h"
+
+namespace sn {
+
+constexpr int kBuffers = 9;  // TOTAL_BUFFERS, /root/reference/src/SangNom2.h:22
+
+// One plane of one launch (all frames of a batch share it; frame f adds f * *_frame_stride).
+struct PlaneArgs {
+    const uint8_t* src;
+    uint8_t* dst;
+    int64_t src_frame_stride;  // bytes
+    int64_t dst_frame_stride;  // bytes
+    int32_t src_pitch;         // bytes
+    int32_t dst_pitch;         // bytes
+    int32_t w;                 // pixels
+    int32_t h_in;              // source rows
+    int32_t h_out;             // destination rows
+    int32_t offset;            // first kept line (0 or 1)
+    int32_t dh;
+    int32_t enabled;           // processPlane[i] || dh
+};
+
+// Scratch pool geometry (src/SangNom2.cpp:287-288,305-310), in elements of T.
+struct PoolArgs {
+    uint8_t* base;             // slot 0
+    int64_t slot_bytes;        // 9 * rows * stride_e * sizeof(T)
+    int32_t stride_e;          // roundup(luma width, 32)
+    int32_t bh;                // bufferHeight; a buffer has bh + 1 rows
+};
+
+struct Context;
+
+// sn_pool_kernels.hip: the three-kernel path over the HBM-resident pool (every format).
+hipError_t launch_assemble(hipStream_t s, const PlaneArgs& p, int bytes, int nframes);
+hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes,
+                             double threshold, int nframes, int slot0);
+
+// sn_fused_u8.hip: fused speculative-tile kernel (8-bit).
+struct FusedPlan;
+bool fused_eligible(const sn_config& c);
+
+}  // namespace sn

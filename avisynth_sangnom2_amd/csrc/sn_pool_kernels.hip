@@ -1,0 +1,293 @@
+// sn_pool_kernels.hip -- the pool path: frame assembly + the three stages as three kernels over
+// an HBM-resident scratch pool laid out exactly like the reference's
+// (/root/reference/src/SangNom2.cpp:287-310: 9 buffers x (bufferHeight + 1) rows x stride_e).
+//
+// This path serves every format and reproduces the reference's shared-pool behaviour by
+// construction (chroma passes sweep the luma-sized pool and see stale luma results, widths that
+// are not a multiple of 32 carry pool state from frame to frame).  It is also the exact fallback
+// of the fused kernel.  Stage 2 is a strictly sequential recurrence over rows
+// (SangNom2.cpp:126-159), so k_smooth walks the rows with one workgroup per buffer.
+#include "sn_internal.h"
+#include "sn_pixel.h"
+
+namespace sn {
+
+// ------------------------------------------------------------------------------------------------
+// Frame assembly: GetFrame's copies, /root/reference/src/SangNom2.cpp:361-391.
+// One thread block row per destination line; the source line of each destination line is decided
+// arithmetically so that the whole assembly is one dependency-free pass.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int assemble_source_row(const PlaneArgs& p, int y)
+{
+    if (!p.enabled) return y;  // plane copied unchanged (SangNom2.cpp:369-374)
+    int yy = y;
+    if (p.offset == 0 && y == p.h_out - 1) yy = p.h_out - 2;  // SangNom2.cpp:380-385
+    if (p.offset == 1 && y == 0) yy = 1;                      // SangNom2.cpp:386-391
+    if (((yy - p.offset) & 1) != 0) return -1;                // interpolated line: written by stage 3
+    return p.dh ? (yy - p.offset) >> 1 : yy;                  // SangNom2.cpp:365 / :376
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_assemble(PlaneArgs p, int row_bytes)
+{
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    const int sy = assemble_source_row(p, y);
+    if (sy < 0) return;
+    const uint8_t* s = p.src + (int64_t)f * p.src_frame_stride + (int64_t)sy * p.src_pitch;
+    uint8_t* d = p.dst + (int64_t)f * p.dst_frame_stride + (int64_t)y * p.dst_pitch;
+    const int nvec = row_bytes / VEC;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
+        if constexpr (VEC == 16) {
+            reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        } else if constexpr (VEC == 4) {
+            reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
+        } else {
+            d[i] = s[i];
+        }
+    }
+    if (blockIdx.x == 0) {  // tail bytes
+        const int t = nvec * VEC + threadIdx.x;
+        if (t < row_bytes) d[t] = s[t];
+    }
+}
+
+hipError_t launch_assemble(hipStream_t st, const PlaneArgs& p, int bytes, int nframes)
+{
+    const int row_bytes = p.w * bytes;
+    auto aligned = [&](int a) {
+        return ((uintptr_t)p.src % a == 0) && ((uintptr_t)p.dst % a == 0) && (p.src_pitch % a == 0) &&
+               (p.dst_pitch % a == 0) && (p.src_frame_stride % a == 0) && (p.dst_frame_stride % a == 0);
+    };
+    const int vec = aligned(16) ? 16 : aligned(4) ? 4 : 1;
+    const int nvec = row_bytes / vec;
+    int gx = (nvec + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, p.h_out, nframes), block(256);
+    if (vec == 16)
+        hipLaunchKernelGGL(k_assemble<16>, grid, block, 0, st, p, row_bytes);
+    else if (vec == 4)
+        hipLaunchKernelGGL(k_assemble<4>, grid, block, 0, st, p, row_bytes);
+    else
+        hipLaunchKernelGGL(k_assemble<1>, grid, block, 0, st, p, row_bytes);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared tap loader: the 14 edge-clamped taps and the four SangNom values of one pixel pair
+// (loadPixel + calculateSangNom, SangNom2.cpp:25-34,60-72,84-103).
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct Taps {
+    using W = typename Px<T>::W;
+    W c[7], n[7];  // index k+3 for tap k = -3..3
+    W f1, f2, b1, b2;
+    __device__ __forceinline__ void load(const T* cl, const T* nl, int x, int w)
+    {
+#pragma unroll
+        for (int k = -3; k <= 3; ++k) {
+            int q = x + k;
+            q = q < 0 ? 0 : (q > w - 1 ? w - 1 : q);
+            c[k + 3] = (W)cl[q];
+            n[k + 3] = (W)nl[q];
+        }
+        f1 = Px<T>::sg(c[2], c[3], c[4]);
+        f2 = Px<T>::sg(n[4], n[3], n[2]);
+        b1 = Px<T>::sg(c[4], c[3], c[2]);
+        b2 = Px<T>::sg(n[2], n[3], n[4]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1: prepareBuffers_c, SangNom2.cpp:74-124.  One thread per pixel of one line pair.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_prepare(PlaneArgs p, PoolArgs pool, int slot0)
+{
+    using P = Px<T>;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= p.w) return;
+    const uint8_t* plane = p.dst + (int64_t)f * p.dst_frame_stride;
+    const T* cl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y) * p.dst_pitch);
+    const T* nl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y + 2) * p.dst_pitch);
+    Taps<T> t;
+    t.load(cl, nl, x, p.w);
+    T* pb = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes);
+    const size_t bufsz = (size_t)pool.stride_e * (pool.bh + 1);
+    const size_t at = (size_t)(y + 1) * pool.stride_e + x;
+    pb[0 * bufsz + at] = (T)P::adiff(t.c[0], t.n[6]);  // ADIFF_M3_P3
+    pb[1 * bufsz + at] = (T)P::adiff(t.c[1], t.n[5]);  // ADIFF_M2_P2
+    pb[2 * bufsz + at] = (T)P::adiff(t.c[2], t.n[4]);  // ADIFF_M1_P1
+    pb[3 * bufsz + at] = (T)P::adiff(t.f1, t.f2);      // SG_FORWARD
+    pb[4 * bufsz + at] = (T)P::adiff(t.c[3], t.n[3]);  // ADIFF_P0_M0
+    pb[5 * bufsz + at] = (T)P::adiff(t.b1, t.b2);      // SG_REVERSE
+    pb[6 * bufsz + at] = (T)P::adiff(t.c[4], t.n[2]);  // ADIFF_P1_M1
+    pb[7 * bufsz + at] = (T)P::adiff(t.c[5], t.n[1]);  // ADIFF_P2_M2
+    pb[8 * bufsz + at] = (T)P::adiff(t.c[6], t.n[0]);  // ADIFF_P3_M3
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2: processBuffers_c, SangNom2.cpp:126-159.  In place, rows 1..bh-1, all stride_e columns.
+// Row r needs the already-filtered row r-1, so one 1024-thread workgroup per (buffer, frame) walks
+// the rows; the vertical 3-row sums go through a double-buffered LDS line for the 7-tap box.
+// Rows r+1 / r+2 are carried in registers so that each pool row is read once.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmoothThreads = 1024;
+constexpr int kSmoothMaxCols = 8;  // columns per thread -> stride_e <= 8192
+
+template <class T, int NC>
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int slot0)
+{
+    using P = Px<T>;
+    using W = typename P::W;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;
+    W* line0 = reinterpret_cast<W*>(smem);
+    W* line1 = line0 + se;
+    const int b = blockIdx.x;
+    const int f = blockIdx.y;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    T* buf = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    const int tid = threadIdx.x;
+
+    W prev[NC], cur[NC], nxt[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int x = tid + k * kSmoothThreads;
+        const bool in = x < se;
+        prev[k] = in ? (W)buf[x] : (W)0;
+        cur[k] = in ? (W)buf[(size_t)se + x] : (W)0;
+        nxt[k] = (in && pool.bh >= 2) ? (W)buf[(size_t)2 * se + x] : (W)0;
+    }
+    for (int r = 1; r < pool.bh; ++r) {
+        W pre[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int x = tid + k * kSmoothThreads;
+            pre[k] = (x < se && r + 2 <= pool.bh) ? (W)buf[(size_t)(r + 2) * se + x] : (W)0;
+        }
+        W* line = (r & 1) ? line1 : line0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int x = tid + k * kSmoothThreads;
+            if (x < se) line[x] = P::sum3(prev[k], cur[k], nxt[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int x = tid + k * kSmoothThreads;
+            if (x < se) {
+                W s;
+                {
+                    const int q0 = x - 3 < 0 ? 0 : x - 3;
+                    const int q1 = x - 2 < 0 ? 0 : x - 2;
+                    s = line[q0] + line[q1];  // left-to-right, SangNom2.cpp:152
+                }
+                s = s + line[x - 1 < 0 ? 0 : x - 1];
+                s = s + line[x];
+                s = s + line[x + 1 > se - 1 ? se - 1 : x + 1];
+                s = s + line[x + 2 > se - 1 ? se - 1 : x + 2];
+                s = s + line[x + 3 > se - 1 ? se - 1 : x + 3];
+                const W o = P::div16(s);
+                buf[(size_t)r * se + x] = (T)o;
+                prev[k] = o;
+            }
+            cur[k] = nxt[k];
+            nxt[k] = pre[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 3: finalizePlane_c, SangNom2.cpp:161-257.  One thread per interpolated pixel.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256)
+k_finalize(PlaneArgs p, PoolArgs pool, int slot0, typename Px<T>::W thr)
+{
+    using P = Px<T>;
+    using W = typename P::W;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= p.w) return;
+    uint8_t* plane = p.dst + (int64_t)f * p.dst_frame_stride;
+    const T* cl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y) * p.dst_pitch);
+    const T* nl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y + 2) * p.dst_pitch);
+    T* ol = reinterpret_cast<T*>(plane + (int64_t)(p.offset + 2 * y + 1) * p.dst_pitch);
+    Taps<T> t;
+    t.load(cl, nl, x, p.w);
+    const T* pb = reinterpret_cast<const T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes);
+    const size_t bufsz = (size_t)pool.stride_e * (pool.bh + 1);
+    const size_t at = (size_t)(y + 1) * pool.stride_e + x;
+    W v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = (W)pb[i * bufsz + at];
+    W m = v[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) m = v[i] < m ? v[i] : m;  // std::min(m, v[i])
+
+    W r = P::avg(t.c[0], t.n[6]);                       // buf[0]: avg(c-3, n+3), lowest priority
+    r = (v[8] == m) ? P::avg(t.c[6], t.n[0]) : r;       // buf[8]: avg(c+3, n-3)
+    r = (v[1] == m) ? P::avg(t.c[1], t.n[5]) : r;
+    r = (v[7] == m) ? P::avg(t.c[5], t.n[1]) : r;
+    r = (v[2] == m) ? P::avg(t.c[2], t.n[4]) : r;
+    r = (v[6] == m) ? P::avg(t.c[4], t.n[2]) : r;
+    r = (v[3] == m) ? P::avg(t.f1, t.f2) : r;
+    r = (v[5] == m) ? P::avg(t.b1, t.b2) : r;
+    r = (v[4] == m || m > thr) ? P::avg(t.c[3], t.n[3]) : r;  // SangNom2.cpp:214
+    ol[x] = (T)r;
+}
+
+template <class T>
+static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const PoolArgs& pool,
+                                      double threshold, int nframes, int slot0)
+{
+    using W = typename Px<T>::W;
+    const int nr = p.h_out / 2 - 1;
+    if (nr > 0) {
+        dim3 grid((p.w + 255) / 256, nr, nframes), block(256);
+        hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, p, pool, slot0);
+    }
+    if (pool.bh > 1) {
+        const int nc = (pool.stride_e + kSmoothThreads - 1) / kSmoothThreads;
+        const size_t lds = (size_t)2 * pool.stride_e * sizeof(W);
+        dim3 grid(kBuffers, nframes), block(kSmoothThreads);
+        hipError_t e = hipSuccess;
+#define SN_SMOOTH(NC)                                                                              \
+    do {                                                                                           \
+        if (lds > 48 * 1024)                                                                       \
+            e = hipFuncSetAttribute((const void*)k_smooth<T, NC>,                                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_smooth<T, NC>), grid, block, lds, st, pool, slot0); \
+    } while (0)
+        if (nc <= 1) SN_SMOOTH(1);
+        else if (nc <= 2) SN_SMOOTH(2);
+        else if (nc <= 4) SN_SMOOTH(4);
+        else SN_SMOOTH(8);
+#undef SN_SMOOTH
+        if (e != hipSuccess) return e;
+    }
+    if (nr > 0) {
+        dim3 grid((p.w + 255) / 256, nr, nframes), block(256);
+        W thr;
+        if constexpr (sizeof(T) == 4) thr = (float)threshold; else thr = (W)threshold;
+        hipLaunchKernelGGL(k_finalize<T>, grid, block, 0, st, p, pool, slot0, thr);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_plane(hipStream_t st, const PlaneArgs& p, const PoolArgs& pool, int bytes,
+                             double threshold, int nframes, int slot0)
+{
+    switch (bytes) {
+    case 1: return launch_pool_plane_t<uint8_t>(st, p, pool, threshold, nframes, slot0);
+    case 2: return launch_pool_plane_t<uint16_t>(st, p, pool, threshold, nframes, slot0);
+    default: return launch_pool_plane_t<float>(st, p, pool, threshold, nframes, slot0);
+    }
+}
+
+}  // namespace sn

@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's filter object for tests and the benchmark.
+
+`SangNom2(clip_format, order, aa, aac, threads, dh, luma, chroma, opt)` keeps the reference's
+argument names, defaults and error text (/root/reference/src/SangNom2.cpp:399-435; README.md:20-57)
+and `get_frame` plays the role of `SangNom2::GetFrame` (src/SangNom2.cpp:332-397).  All pixel work is
+done by libsangnom_hip.so through the C ABI; torch is used only to hold device memory.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+
+class SangNomError(RuntimeError):
+    """Raised where the reference would call env->ThrowError, with the same message."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+@dataclass
+class ClipFormat:
+    """The part of AviSynth's VideoInfo the filter looks at (planar Y / YUV only)."""
+    width: int
+    height: int
+    bytes: int = 1       # vi.ComponentSize()
+    bits: int = 8        # vi.BitsPerComponent()
+    planes: int = 1      # vi.NumComponents() clipped to 3
+    subw: int = 0        # log2 chroma subsampling
+    subh: int = 0
+
+    @property
+    def dtype(self):
+        return {1: np.uint8, 2: np.uint16, 4: np.float32}[self.bytes]
+
+
+_FORMATS = {
+    "Y8": dict(bytes=1, bits=8, planes=1), "Y10": dict(bytes=2, bits=10, planes=1),
+    "Y16": dict(bytes=2, bits=16, planes=1), "Y32": dict(bytes=4, bits=32, planes=1),
+    "YUV420P8": dict(bytes=1, bits=8, planes=3, subw=1, subh=1),
+    "YUV420P10": dict(bytes=2, bits=10, planes=3, subw=1, subh=1),
+    "YUV420P16": dict(bytes=2, bits=16, planes=3, subw=1, subh=1),
+    "YUV422P8": dict(bytes=1, bits=8, planes=3, subw=1, subh=0),
+    "YUV444P8": dict(bytes=1, bits=8, planes=3), "YUV444P16": dict(bytes=2, bits=16, planes=3),
+    "YUV444PS": dict(bytes=4, bits=32, planes=3), "YUV420PS": dict(bytes=4, bits=32, planes=3, subw=1, subh=1),
+}
+
+
+def clip_format(name: str, width: int, height: int) -> ClipFormat:
+    """ClipFormat from an AviSynth+ pixel_type name such as "YUV420P8" or "Y16"."""
+    return ClipFormat(width=width, height=height, **_FORMATS[name])
+
+
+class SangNom2:
+    """One filter instance == one sn_context (its own stream and device pool)."""
+
+    def __init__(self, clip: ClipFormat, order: int = 1, aa: int = 48, aac: int = 0, threads: int = 0,
+                 dh: bool = False, luma: bool = True, chroma: bool = True, opt: int = -1,
+                 device: int = 0, max_batch: int = 1, mode: str = "auto", stream: int | None = None):
+        # `threads` is a dummy in the reference (README.md:40-41); `opt` picks its CPU code path.
+        if opt < -1 or opt > 1:
+            raise SangNomError(capi.SN_ERR_CONFIG, "SangNom2: opt must be between -1..2.")  # sic, SangNom2.cpp:420
+        self.clip = clip
+        self._lib = capi.load()
+        cfg = capi.SnConfig(
+            struct_size=ctypes.sizeof(capi.SnConfig), width=clip.width, height=clip.height,
+            bytes_per_sample=clip.bytes, bits_per_sample=clip.bits, num_planes=clip.planes,
+            sub_w=clip.subw, sub_h=clip.subh, order=order, aa=aa, aac=aac, dh=int(dh), luma=int(luma),
+            chroma=int(chroma), device=device, max_batch=max_batch, mode=capi.MODES[mode], reserved=0,
+            stream=stream)
+        self._cfg = cfg
+        self.max_batch = max_batch
+        self.device = device
+        self._h = ctypes.c_void_p()
+        rc = self._lib.sn_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != capi.SN_OK:
+            self._h = None
+            raise SangNomError(rc, self._lib.sn_last_error(None).decode())
+        self.out_height = clip.height * 2 if dh else clip.height
+
+    # -- geometry -------------------------------------------------------------------------------
+    @property
+    def nplanes(self) -> int:
+        return min(self.clip.planes, 3)
+
+    def plane_shape_in(self, p: int):
+        return (self.clip.height >> (self.clip.subh if p else 0), self.clip.width >> (self.clip.subw if p else 0))
+
+    def plane_shape_out(self, p: int):
+        return (self.out_height >> (self.clip.subh if p else 0), self.clip.width >> (self.clip.subw if p else 0))
+
+    # -- life cycle -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != capi.SN_OK:
+            raise SangNomError(rc, self._lib.sn_last_error(self._h).decode())
+
+    def info(self) -> capi.SnInfo:
+        i = capi.SnInfo(struct_size=ctypes.sizeof(capi.SnInfo))
+        self._check(self._lib.sn_get_info(self._h, ctypes.byref(i)))
+        return i
+
+    def stream_handle(self) -> int:
+        return self._lib.sn_get_stream(self._h)
+
+    def synchronize(self):
+        self._check(self._lib.sn_synchronize(self._h))
+
+    def read_pool(self, slot: int = 0) -> np.ndarray:
+        i = self.info()
+        out = np.empty((9, i.pool_rows, i.pool_stride), dtype=self.clip.dtype)
+        self._check(self._lib.sn_debug_read_pool(self._h, slot, out.ctypes.data, out.nbytes))
+        return out
+
+    # -- GetFrame -------------------------------------------------------------------------------
+    def get_frame(self, src, parity: int = 1, dst=None):
+        """Host planes (numpy 2-D arrays, any row pitch) in, host planes out (synchronous)."""
+        n = self.nplanes
+        if dst is None:
+            dst = [np.zeros(self.plane_shape_out(p), dtype=self.clip.dtype) for p in range(n)]
+        sp, dp = (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)()
+        spi, dpi = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 3)()
+        for p in range(n):
+            s, d = src[p], dst[p]
+            if s.dtype != self.clip.dtype or d.dtype != self.clip.dtype:
+                raise TypeError("plane dtype does not match the clip format")
+            if s.shape != self.plane_shape_in(p) or d.shape != self.plane_shape_out(p):
+                raise ValueError(f"plane {p}: shape {s.shape}->{d.shape}, expected "
+                                 f"{self.plane_shape_in(p)}->{self.plane_shape_out(p)}")
+            if s.strides[1] != self.clip.bytes or d.strides[1] != self.clip.bytes:
+                raise ValueError("planes must be contiguous along x")
+            sp[p], dp[p], spi[p], dpi[p] = s.ctypes.data, d.ctypes.data, s.strides[0], d.strides[0]
+        self._check(self._lib.sn_process_host(self._h, sp, spi, dp, dpi, int(parity)))
+        return dst
+
+    def get_frame_device(self, src, dst, parity: int = 1):
+        """Device planes: torch tensors [H, W] on this context's GPU.  Asynchronous."""
+        return self.process_batch([s.unsqueeze(0) for s in src], [d.unsqueeze(0) for d in dst], [parity])
+
+    def process_batch(self, src, dst, parity=None):
+        """src[p] / dst[p]: torch tensors [N, H_p, W_p] (device-resident, x-contiguous).
+        Frame f of plane p lives at tensor[f].  Asynchronous on the context's stream."""
+        n = self.nplanes
+        N = src[0].shape[0]
+        sp, dp = (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)()
+        spi, dpi = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 3)()
+        sfs, dfs = (ctypes.c_int64 * 3)(), (ctypes.c_int64 * 3)()
+        B = self.clip.bytes
+        for p in range(n):
+            s, d = src[p], dst[p]
+            if tuple(s.shape[1:]) != self.plane_shape_in(p) or tuple(d.shape[1:]) != self.plane_shape_out(p):
+                raise ValueError(f"plane {p}: bad shape {tuple(s.shape)} -> {tuple(d.shape)}")
+            if s.shape[0] != N or d.shape[0] != N:
+                raise ValueError("all planes must carry the same number of frames")
+            if s.stride(2) != 1 or d.stride(2) != 1 or s.element_size() != B or d.element_size() != B:
+                raise ValueError("planes must be x-contiguous tensors of the clip's sample type")
+            if not s.is_cuda or not d.is_cuda:
+                raise ValueError("process_batch needs device-resident tensors (use get_frame for host planes)")
+            sp[p], dp[p] = s.data_ptr(), d.data_ptr()
+            spi[p], dpi[p] = s.stride(1) * B, d.stride(1) * B
+            sfs[p], dfs[p] = s.stride(0) * B, d.stride(0) * B
+        par = None
+        if parity is not None:
+            par = (ctypes.c_int32 * N)(*[int(x) for x in parity])
+        self._check(self._lib.sn_process_device_strided(self._h, N, sp, sfs, spi, dp, dfs, dpi, par))
+        return dst
+
+
+def SangNom(clip: ClipFormat, order: int = 1, aa: int = 48, opt: int = -1, **kw) -> SangNom2:
+    """Legacy entry point (src/SangNom2.cpp:437-472): order 0/1/2 means bottom/top/double-rate and
+    is remapped to SangNom2's 2/1/0.  The reference reads args[3] (`opt`) as aac because of an
+    out-of-range argument read; that quirk is NOT reproduced: aac is 0 here."""
+    if order < 0 or order > 2:
+        raise SangNomError(capi.SN_ERR_CONFIG, "SangNom: order must be between 0..2.")
+    return SangNom2(clip, order=(2, 1, 0)[order], aa=aa, aac=0, opt=opt, **kw)

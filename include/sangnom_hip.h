@@ -1,0 +1,142 @@
+/*
+ * sangnom_hip.h -- C ABI of libsangnom_hip.so, the MI355X (gfx950) implementation of the
+ * SangNom2 edge-directed interpolation hot path.
+ *
+ * What this boundary replaces in the reference (Asd-g/AviSynth-SangNom2 v0.6.1):
+ *   - the per-plane kernel entry   void (SangNom2::*process)(dstp, dstStride, w, h, offset, plane)
+ *                                  src/SangNom2.h:58, called at src/SangNom2.cpp:393
+ *   - its drivers                  SangNom2::sangnom_c  src/SangNom2.cpp:259-273
+ *                                  SangNom2::sangnom_sse src/SangNom2_SSE2.cpp:1258-1272
+ *   - the frame assembly around it SangNom2::GetFrame   src/SangNom2.cpp:346-394
+ *   - instance state               ctor: thresholds, pool geometry  src/SangNom2.cpp:275-310
+ *   - argument validation          Create_SangNom2      src/SangNom2.cpp:407-422
+ *
+ * The reference has no FFI of its own (it is one C++ plugin); the functions below are what a
+ * plugin adapter (host/sangnom2_avs_plugin.cpp) binds instead of calling (this->*process)().
+ * Plain C: pointers, sizes and integer return codes only; no exceptions cross this boundary and
+ * no torch / HIP types appear in the signatures (a hipStream_t travels as void*).
+ *
+ * Results are bit-exact to the reference's opt=0 path for 8..16-bit integer formats and for
+ * 32-bit float, under the conventions that make the reference's output defined
+ * (zero-filled scratch pool, one context == one filter instance, frames in call order).
+ *
+ * There is NO CPU fallback: every entry point that computes needs a HIP device and fails with
+ * SN_ERR_NO_DEVICE / SN_ERR_HIP otherwise.
+ */
+#ifndef SANGNOM_HIP_H
+#define SANGNOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_ABI_VERSION 1
+
+typedef struct sn_context sn_context;
+
+/* Return codes. */
+enum {
+    SN_OK = 0,
+    SN_ERR_INVALID_ARG = 1, /* null pointer, bad struct_size, bad pitch ...                   */
+    SN_ERR_CONFIG = 2,      /* rejected by the reference's own checks; message = its text     */
+    SN_ERR_HIP = 3,         /* a HIP runtime call failed; message names it                    */
+    SN_ERR_NO_DEVICE = 4,   /* no usable HIP device                                           */
+    SN_ERR_UNSUPPORTED = 5  /* geometry outside what the kernels handle (see sn_create)       */
+};
+
+/* Execution path selection (sn_config.mode). */
+enum {
+    SN_MODE_AUTO = 0,   /* fused tile kernel where eligible, else the pool path               */
+    SN_MODE_POOL = 1,   /* always the three-kernel path over the HBM-resident pool            */
+    SN_MODE_FUSED = 2   /* require the fused kernel; sn_create fails if not eligible          */
+};
+
+/* Clip format + the script arguments of SangNom2(clip, order, aa, aac, threads, dh, luma,
+ * chroma, opt)  (src/SangNom2.cpp:399-435, README.md:20-57).  `threads` is a dummy in the
+ * reference and `opt` selects its CPU code path; neither exists here. */
+typedef struct sn_config {
+    int32_t struct_size;      /* = sizeof(sn_config)                                         */
+    int32_t width;            /* luma width, pixels                                          */
+    int32_t height;           /* luma height of the INPUT clip (before dh doubles it)        */
+    int32_t bytes_per_sample; /* 1, 2 or 4 (float)              vi.ComponentSize()           */
+    int32_t bits_per_sample;  /* 8..16 or 32                    vi.BitsPerComponent()        */
+    int32_t num_planes;       /* 1 (Y) or 3 (YUV); alpha is never touched (SangNom2.cpp:347) */
+    int32_t sub_w;            /* log2 horizontal chroma subsampling                          */
+    int32_t sub_h;            /* log2 vertical chroma subsampling                            */
+    int32_t order;            /* 0 = field by parity, 1 = keep top, 2 = keep bottom          */
+    int32_t aa;               /* luma anti-aliasing strength 0..128 (default 48)             */
+    int32_t aac;              /* chroma anti-aliasing strength 0..128 (default 0)            */
+    int32_t dh;               /* double the height                                           */
+    int32_t luma;             /* process luma (default 1)                                    */
+    int32_t chroma;           /* process chroma (default 1)                                  */
+    int32_t device;           /* HIP device ordinal                                          */
+    int32_t max_batch;        /* frames one sn_process_device_strided call may carry (>= 1)  */
+    int32_t mode;             /* SN_MODE_*                                                   */
+    int32_t reserved;
+    void*   stream;           /* hipStream_t to run on; NULL = the context creates its own   */
+} sn_config;
+
+/* Geometry and counters of a live context. */
+typedef struct sn_info {
+    int32_t struct_size;
+    int32_t out_height;       /* luma output height                                          */
+    int32_t pool_stride;      /* elements per pool row  = roundup(width, 32)                 */
+    int32_t pool_rows;        /* bufferHeight + 1                                            */
+    int32_t fused_eligible;   /* 1 if the fused kernel serves this configuration             */
+    int32_t history_free;     /* 1 if a frame's result cannot depend on earlier frames       */
+    int64_t frames;           /* frames processed so far                                     */
+    int64_t fused_frames;     /* ... of which by the fused kernel                            */
+    int64_t fused_tiles_rejected; /* speculative tiles whose verification failed (redone)    */
+    double  threshold[3];     /* aaf[plane] after conversion to the sample type              */
+} sn_info;
+
+/* Create_SangNom2's argument checks, same order, same message text (src/SangNom2.cpp:407-422).
+ * Returns SN_OK or SN_ERR_CONFIG (+ message). */
+int sn_validate(const sn_config* cfg, char* msg, size_t msg_len);
+
+/* Constructor of the filter instance (src/SangNom2.cpp:275-330): thresholds, pool geometry,
+ * device pool (zero-filled), stream.  Runs sn_validate first. */
+int sn_create(const sn_config* cfg, sn_context** out);
+void sn_destroy(sn_context* ctx);
+
+/* Text of the last error on this context; with ctx == NULL, of the last failed sn_create /
+ * sn_validate on the calling thread.  Never NULL. */
+const char* sn_last_error(const sn_context* ctx);
+
+/* One GetFrame (src/SangNom2.cpp:332-397) with HOST planes: H2D, kernels, D2H, synchronous.
+ * src planes have the input geometry, dst planes the output geometry; pitches in bytes, any
+ * value >= row size.  parity = child->GetParity(n), used only when order == 0. */
+int sn_process_host(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3],
+                    void* const dst[3], const int32_t dst_pitch[3], int32_t parity);
+
+/* The same with DEVICE planes, asynchronous on the context's stream. */
+int sn_process_device(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3],
+                      void* const dst[3], const int32_t dst_pitch[3], int32_t parity);
+
+/* nframes (<= max_batch) device-resident frames in one call: frame f's plane p starts at
+ * src[p] + f * src_frame_stride[p] bytes (likewise dst).  Equivalent to nframes calls of
+ * sn_process_device in order; when the configuration is history-free the frames are processed
+ * concurrently.  parity may be NULL (= all 1). */
+int sn_process_device_strided(sn_context* ctx, int32_t nframes,
+                              const void* const src[3], const int64_t src_frame_stride[3],
+                              const int32_t src_pitch[3],
+                              void* const dst[3], const int64_t dst_frame_stride[3],
+                              const int32_t dst_pitch[3], const int32_t* parity);
+
+int sn_synchronize(sn_context* ctx);
+void* sn_get_stream(sn_context* ctx); /* the hipStream_t the context launches on */
+int sn_get_info(sn_context* ctx, sn_info* info);
+
+/* Test hook: copy the device scratch pool of batch slot `slot` to host memory
+ * (9 x pool_rows x pool_stride elements).  Synchronises the stream. */
+int sn_debug_read_pool(sn_context* ctx, int32_t slot, void* host_dst, size_t bytes);
+
+int sn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

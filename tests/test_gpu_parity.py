@@ -1,0 +1,166 @@
+"""GPU parity: libsangnom_hip.so (through the C ABI) against the CPU oracle, bit-exact.
+
+Reads like the tests the reference never had: construct SangNom2(clip, order, aa, aac, ..., dh,
+luma, chroma), request frames, compare with opt=0 semantics
+(/root/reference/src/SangNom2.cpp:259-273, :332-397).  Float planes are compared on their bit
+patterns (north_star allows 1 ulp; we hold 0).
+"""
+import numpy as np
+import pytest
+
+from avisynth_sangnom2_amd import ClipFormat, SangNom2, SangNomError, clip_format, synth
+from oracle.oracle import Oracle
+from tests.util import describe_diff, make_frames, oracle_cfg, same
+
+pytestmark = pytest.mark.gpu
+
+PATTERNS = ("noise", "checker", "sine", "edges")
+
+# (pixel_type, width, height, filter kwargs)
+CASES = [
+    ("Y8", 64, 32, {}),
+    ("Y8", 256, 64, dict(order=2)),
+    ("Y8", 192, 48, dict(order=0, aa=128)),
+    ("Y8", 100, 40, dict(aa=1)),                       # width % 32 != 0: pool keeps state
+    ("Y8", 1056, 34, dict(aa=0)),                      # wider than one smoothing pass of 1024 threads
+    ("Y10", 96, 36, dict(aa=20)),
+    ("Y16", 128, 64, {}),
+    ("Y16", 72, 32, dict(order=2, aa=77)),
+    ("Y32", 64, 48, {}),
+    ("Y32", 40, 32, dict(order=2, aa=10)),
+    ("YUV420P8", 128, 64, dict(aac=48)),
+    ("YUV420P8", 96, 32, dict(aac=0, order=2)),
+    ("YUV420P8", 128, 32, dict(chroma=False)),
+    ("YUV420P8", 128, 32, dict(luma=False, aac=33)),   # chroma sees the previous frame's pool
+    ("YUV420P16", 128, 64, dict(aac=48)),
+    ("YUV422P8", 64, 32, dict(aac=48)),
+    ("YUV444P8", 64, 32, dict(aac=100, order=0)),
+    ("YUV444PS", 64, 24, dict(dh=True, aac=48)),
+    ("YUV420P8", 64, 32, dict(dh=True, aac=48)),
+    ("YUV420P16", 80, 32, dict(dh=True, luma=False, aac=5)),
+]
+
+
+def _run_case(fmt, w, h, kw, pattern, nframes=3, mode="auto"):
+    clip = clip_format(fmt, w, h)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    with SangNom2(clip, device=0, mode=mode, **kw) as flt:
+        for f, src in enumerate(make_frames(clip, pattern, nframes, seed0=7)):
+            parity = f & 1
+            want = ora.process(src, parity=parity)
+            got = flt.get_frame(src, parity=parity)
+            for p in range(len(want)):
+                assert same(want[p], got[p]), (
+                    f"{fmt} {w}x{h} {kw} {pattern} frame {f} plane {p}: " + describe_diff(want[p], got[p]))
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}-{i}" for i, c in enumerate(CASES)])
+@pytest.mark.parametrize("pattern", PATTERNS)
+def test_host_frames_match_oracle(hip_lib, fmt, w, h, kw, pattern):
+    _run_case(fmt, w, h, kw, pattern)
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", CASES[:4] + CASES[10:13], ids=lambda v: str(v) if not isinstance(v, dict) else "kw")
+def test_pool_mode_matches_oracle(hip_lib, fmt, w, h, kw):
+    _run_case(fmt, w, h, kw, "noise", mode="pool")
+
+
+def test_pool_contents_match_oracle(hip_lib):
+    """The smoothed pool itself (stage 1 + 2) is bit-identical, including rows 0 / bh and stale cells."""
+    clip = clip_format("YUV420P8", 96, 32)
+    ora = Oracle(oracle_cfg(clip, aac=48))
+    with SangNom2(clip, aac=48, mode="pool") as flt:
+        for f, src in enumerate(make_frames(clip, "noise", 2)):
+            ora.process(src)
+            flt.get_frame(src)
+            assert np.array_equal(ora.pool(), flt.read_pool(0)), f"pool differs after frame {f}"
+
+
+def test_pitched_host_planes(hip_lib):
+    """Arbitrary, differing src/dst pitches (AviSynth frames are pitched); padding is left alone."""
+    clip = clip_format("YUV420P8", 96, 32)
+    kw = dict(aac=48, order=2)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    src = synth.frame(clip, "edges", seed=3)
+    want = ora.process(src)
+    with SangNom2(clip, **kw) as flt:
+        psrc, pdst = [], []
+        for p, s in enumerate(src):
+            big = np.full((s.shape[0], s.shape[1] + 13 + 16 * p), 0xAB, dtype=s.dtype)
+            big[:, :s.shape[1]] = s
+            psrc.append(big[:, :s.shape[1]])
+            d = np.full((flt.plane_shape_out(p)[0], s.shape[1] + 64 - 7 * p), 0xCD, dtype=s.dtype)
+            pdst.append(d[:, :s.shape[1]])
+        got = flt.get_frame(psrc, dst=pdst)
+        for p in range(3):
+            assert same(want[p], got[p])
+            assert (pdst[p].base[:, want[p].shape[1]:] == 0xCD).all(), "dst padding was overwritten"
+
+
+def test_device_batch_matches_oracle(hip_lib):
+    """sn_process_device_strided on device-resident frames == per-frame oracle (history-free config)."""
+    import torch
+    clip = clip_format("YUV420P8", 128, 64)
+    kw = dict(aac=48)
+    N = 5
+    frames = make_frames(clip, "noise", N, seed0=11)
+    dev = torch.device("cuda:0")
+    with SangNom2(clip, max_batch=N, **kw) as flt:
+        assert flt.info().history_free == 1
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).to(dev) for p in range(3)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(3)]
+        torch.cuda.synchronize()
+        parity = [1, 0, 1, 1, 0]
+        flt.process_batch(src, dst, parity)
+        flt.synchronize()
+        for f in range(N):
+            ora = Oracle(oracle_cfg(clip, **kw))  # fresh instance per frame: history-free
+            want = ora.process(frames[f], parity=parity[f])
+            for p in range(3):
+                assert same(want[p], dst[p][f].cpu().numpy()), f"frame {f} plane {p}"
+
+
+def test_device_batch_history_carrying(hip_lib):
+    """width % 32 != 0: a batch must behave like sequential frames on ONE instance (pool state carries)."""
+    import torch
+    clip = clip_format("Y8", 100, 40)
+    N = 4
+    frames = make_frames(clip, "noise", N, seed0=5)
+    dev = torch.device("cuda:0")
+    ora = Oracle(oracle_cfg(clip))
+    with SangNom2(clip, max_batch=N) as flt:
+        assert flt.info().history_free == 0
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).to(dev)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(0), dtype=torch.uint8, device=dev)]
+        flt.process_batch(src, dst)
+        flt.synchronize()
+        for f in range(N):
+            want = ora.process(frames[f])
+            assert same(want[0], dst[0][f].cpu().numpy()), f"frame {f}"
+
+
+def test_validation_errors_are_the_references(hip_lib):
+    """Create_SangNom2's checks and message text, /root/reference/src/SangNom2.cpp:407-422."""
+    cases = [
+        (clip_format("Y8", 64, 31), {}, "SangNom2: height must be even."),
+        (clip_format("YUV420P8", 64, 34), {}, "SangNom2: height must be mod4."),
+        (clip_format("Y8", 64, 32), dict(order=3), "SangNom2: order must be between 0..2."),
+        (clip_format("Y8", 64, 32), dict(aa=129), "SangNom2: aa must be between 0..128."),
+        (clip_format("Y8", 64, 32), dict(aac=-1), "SangNom2: aac must be between 0..128."),
+        (clip_format("Y8", 64, 32), dict(opt=2), "SangNom2: opt must be between -1..2."),
+    ]
+    for clip, kw, text in cases:
+        with pytest.raises(SangNomError) as ei:
+            SangNom2(clip, **kw)
+        assert str(ei.value) == text
+
+
+def test_flat_and_extreme_inputs(hip_lib):
+    """Known answers: a flat plane stays flat; all-max and all-zero planes survive the wrap paths."""
+    for fmt, vals in (("Y8", (0, 255, 128)), ("Y16", (0, 65535, 40000)), ("Y32", (0.0, 1.0, 0.25))):
+        clip = clip_format(fmt, 64, 32)
+        with SangNom2(clip) as flt:
+            for v in vals:
+                src = [np.full((32, 64), v, dtype=clip.dtype)]
+                out = flt.get_frame(src)
+                assert (out[0] == src[0]).all()

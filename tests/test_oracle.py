@@ -1,0 +1,220 @@
+"""CPU tests of the oracle itself (no GPU).
+
+The oracle is a restatement of /root/reference/src/SangNom2.cpp:25-397 (opt=0).  PARITY UNPINNED:
+the reference ships no fixtures and cannot be built here, so these tests pin the oracle against
+(1) an independent numpy restatement written in a different style, (2) properties and known
+answers that follow directly from the reference's source text, (3) committed regression vectors.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from avisynth_sangnom2_amd import clip_format, synth
+from oracle.oracle import Config, Oracle, validate
+from oracle.sangnom_numpy import NumpySangNom
+from tests.util import describe_diff, same
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CROSS = [
+    dict(width=64, height=32),
+    dict(width=72, height=36, order=2),
+    dict(width=100, height=48, order=0, aa=128),
+    dict(width=33, height=20, aa=3),
+    dict(width=96, height=40, bytes=2, bits=16),
+    dict(width=90, height=40, bytes=2, bits=10, aa=1),
+    dict(width=64, height=32, bytes=4, bits=32),
+    dict(width=64, height=32, planes=3, subw=1, subh=1, aac=48),
+    dict(width=80, height=32, planes=3, subw=1, subh=1, aac=48, bytes=2, bits=16, order=2),
+    dict(width=64, height=24, planes=3, bytes=4, bits=32, dh=True, aac=20),
+    dict(width=64, height=32, planes=3, subw=1, subh=1, chroma=False),
+    dict(width=64, height=32, planes=3, subw=1, subh=0, luma=False, aac=30),
+    dict(width=64, height=32, planes=3, subw=1, subh=1, luma=False, aac=30),
+    dict(width=64, height=32, aa=0),
+]
+
+
+@pytest.mark.parametrize("kw", CROSS, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+@pytest.mark.parametrize("pattern", ["noise", "checker", "sine", "edges"])
+def test_c_oracle_equals_numpy_restatement(kw, pattern):
+    cfg = Config(**kw)
+    c_side, np_side = Oracle(cfg), NumpySangNom(**kw)
+    for f in range(3):  # several frames on ONE instance: pool state carries over
+        src = synth.frame(cfg, pattern, seed=f + 1)
+        a = c_side.process(src, parity=f & 1)
+        b = np_side.get_frame(src, parity=f & 1)
+        for p in range(len(a)):
+            assert same(a[p], b[p]), f"frame {f} plane {p}: " + describe_diff(a[p], b[p])
+    # the scratch pools agree too (int64 / float32 working copies on the numpy side)
+    assert np.array_equal(c_side.pool().astype(np_side.pool.dtype), np_side.pool)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+def test_regression_vectors(path):
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    clip = clip_format(meta["fmt"], meta["width"], meta["height"])
+    ora = Oracle(Config(width=clip.width, height=clip.height, bytes=clip.bytes, bits=clip.bits, planes=clip.planes,
+                        subw=clip.subw, subh=clip.subh, **meta["kw"]))
+    for f in range(meta["nframes"]):
+        src = synth.frame(clip, meta["pattern"], seed=meta["seed0"] + f)
+        for p in range(len(src)):
+            assert same(src[p], z[f"in_f{f}_p{p}"]), "synthetic generator changed"
+        out = ora.process(src, parity=(f + 1) & 1)
+        for p in range(len(out)):
+            assert same(out[p], z[f"out_f{f}_p{p}"]), f"{path} frame {f} plane {p}"
+
+
+# ---- known answers derived from the reference source ------------------------------------------------
+
+@pytest.mark.parametrize("bytes_,bits,vals", [(1, 8, (0, 1, 128, 255)), (2, 16, (0, 65535, 777)), (2, 10, (1023,)),
+                                              (4, 32, (0.0, 1.0, 0.37))])
+def test_flat_plane_is_a_fixed_point(bytes_, bits, vals):
+    """Every difference buffer is 0 (calculateSangNom(v,v,v) == v, SangNom2.cpp:60-72), the minimum is
+    buf[4], so each interpolated pixel is avg(v, v) == v (SangNom2.cpp:214-217)."""
+    cfg = Config(width=40, height=16, bytes=bytes_, bits=bits)
+    ora = Oracle(cfg)
+    for v in vals:
+        src = [np.full((16, 40), v, dtype=cfg.dtype)]
+        out = ora.process(src)
+        assert (out[0] == src[0]).all()
+        assert not ora.pool().any()
+
+
+@pytest.mark.parametrize("order,parity,offset", [(1, 0, 0), (1, 1, 0), (2, 0, 1), (2, 1, 1), (0, 1, 0), (0, 0, 1)])
+def test_field_assembly(order, parity, offset):
+    """GetFrame keeps field `offset`, duplicates the one border line (SangNom2.cpp:336-341,376-391)."""
+    cfg = Config(width=64, height=20, order=order)
+    src = synth.frame(cfg, "noise", seed=3)
+    out = Oracle(cfg).process(src, parity=parity)[0]
+    assert np.array_equal(out[offset::2], src[0][offset::2])
+    if offset == 0:
+        assert np.array_equal(out[-1], src[0][-2])
+    else:
+        assert np.array_equal(out[0], src[0][1])
+
+
+def test_double_height_keeps_every_source_line():
+    cfg = Config(width=64, height=12, dh=True, planes=3, subw=1, subh=1, aac=10)
+    src = synth.frame(cfg, "sine", seed=2)
+    out = Oracle(cfg).process(src)
+    for p in range(3):
+        assert out[p].shape[0] == 2 * src[p].shape[0]
+        assert np.array_equal(out[p][0::2], src[p])
+        assert np.array_equal(out[p][-1], src[p][-1])
+
+
+def test_disabled_planes_are_copied():
+    cfg = Config(width=64, height=16, planes=3, subw=1, subh=1, luma=False, chroma=True, aac=40)
+    src = synth.frame(cfg, "noise", seed=9)
+    out = Oracle(cfg).process(src)
+    assert np.array_equal(out[0], src[0])
+    assert not np.array_equal(out[1], src[1])
+
+
+def test_threshold_values():
+    """aaf = aa*21/16 * 2^(bits-8), truncated to T; /256 for float (SangNom2.cpp:280-282)."""
+    assert Oracle(Config(width=32, height=8, aa=48)).threshold(0) == 63
+    assert Oracle(Config(width=32, height=8, aa=1)).threshold(0) == 1          # 1.3125 -> 1
+    assert Oracle(Config(width=32, height=8, aa=128)).threshold(0) == 168
+    assert Oracle(Config(width=32, height=8, bytes=2, bits=16, aa=48)).threshold(0) == 16128
+    assert Oracle(Config(width=32, height=8, bytes=2, bits=10, aa=48)).threshold(0) == 252
+    assert Oracle(Config(width=32, height=8, bytes=4, bits=32, aa=48)).threshold(0) == 0.24609375
+    o = Oracle(Config(width=32, height=8, planes=3, aa=48, aac=16))
+    assert (o.threshold(0), o.threshold(1), o.threshold(2)) == (63, 21, 21)
+
+
+def test_aa_zero_only_switches_on_exact_zero_minimum():
+    """With aa=0 the threshold is 0: `minBuf > aaf` sends every pixel whose minimum cost is non-zero to
+    the plain vertical average (SangNom2.cpp:214)."""
+    cfg = Config(width=64, height=16, aa=0)
+    src = synth.frame(cfg, "noise", seed=4)
+    ora = Oracle(cfg)
+    out = ora.process(src)[0]
+    pool = ora.pool()
+    m = pool[:, 1:8, :64].min(axis=0)
+    vert = ((src[0][0:14:2].astype(int) + src[0][2:16:2].astype(int) + 1) >> 1).astype(np.uint8)
+    sel = m > 0
+    assert sel.any()
+    assert np.array_equal(out[1:15:2][sel], vert[sel])
+
+
+def test_wrap_not_saturate():
+    """opt=0 wraps where the SSE2 path saturates (SangNom2.cpp:63-64,152).  A 0/255 vertical bar pattern
+    drives the smoothed sums past 255*16; the pool must hold the value modulo 256."""
+    cfg = Config(width=32, height=8, aa=48)
+    src = [np.zeros((8, 32), np.uint8)]
+    src[0][0::4] = 255  # kept lines alternate 255 / 0 -> |c0 - n0| = 255 on every row pair
+    ora = Oracle(cfg)
+    ora.process(src)
+    p4 = ora.pool()[4]
+    # row 1: S = 0 + 255 + 255 = 510 on all 32 columns, box = 7*510 = 3570, /16 = 223
+    assert (p4[1] == 223).all()
+    # row 2: S = 223 + 255 + 255 = 733, box = 5131, /16 = 320 -> wraps to 64 (saturation would give 255)
+    assert (p4[2] == 64).all()
+    # row 3 (last filtered row, bh = 4): S = 64 + 255 + 0 (row bh is never written) = 319 -> 2233/16 = 139
+    assert (p4[3] == 139).all()
+
+
+def test_sangnom_value_arithmetic_shift_and_wrap():
+    """calculateSangNom: (4*p1 + 5*p2 - p3) >> 3 is an arithmetic shift on a negative sum, then wraps into T
+    (SangNom2.cpp:60-65).  p = (0, 0, 255) gives -255 >> 3 = -32 -> 224; p = (255, 255, 0) gives 286 -> 30."""
+    cfg = Config(width=32, height=4, aa=48)
+    src = [np.zeros((4, 32), np.uint8)]
+    src[0][0, 16:] = 255  # c = step up at x=16; n = 0
+    ora = Oracle(cfg)
+    ora.process(src)
+    # bh = 2: row 1 is filtered once from rows 0 (zero), 1 (stage 1) and 2 (zero); recover stage 1 by
+    # re-deriving it: at x = 15: f1 = sg(c14, c15, c16) = sg(0, 0, 255) = 224, f2 = 0 -> D3 = 224
+    #                 at x = 16: f1 = sg(c15, c16, c17) = sg(0, 255, 255) = (1275 - 255) >> 3 = 127
+    #                 at x = 15: b1 = sg(c16, c15, c14) = sg(255, 0, 0) = 127; x = 16: sg(255, 255, 0) = 286 -> 30
+    from oracle.sangnom_numpy import NumpySangNom
+    n = NumpySangNom(width=32, height=4)
+    c = src[0][0].astype(np.int64)
+    tc = n._taps(c)
+    f1 = n._sg(tc[-1], tc[0], tc[1])
+    b1 = n._sg(tc[1], tc[0], tc[-1])
+    assert f1[15] == 224 and f1[16] == 127 and f1[17] == 255
+    assert b1[15] == 127 and b1[16] == 30 and b1[14] == 0
+    # and the C oracle used the same numbers: row 1 of buffer 3 is box7(D3)/16 with D3 = |f1 - 0|
+    d3 = f1
+    sp = np.pad(d3, 3, mode="edge")
+    box = sum(sp[k:k + 32] for k in range(7))
+    assert np.array_equal(ora.pool()[3][1].astype(np.int64), (box // 16) % 256)
+
+
+def test_diagonal_edge_is_reconstructed():
+    """Domain property: a clean one-pixel-per-line diagonal edge has zero cost along its own direction
+    (ADIFF_M1_P1 for this slope), so the interpolated lines continue the diagonal exactly."""
+    h, w = 40, 96
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.where(x >= 20 + y, 200, 30).astype(np.uint8)
+    cfg = Config(width=w, height=h, aa=48)
+    out = Oracle(cfg).process([img])[0]
+    assert np.array_equal(out[:-1], img[:-1])
+
+
+def test_validation_messages():
+    """Create_SangNom2's checks in order, with its text (SangNom2.cpp:407-422)."""
+    assert validate(Config(width=64, height=32)) == ""
+    assert validate(Config(width=64, height=31)) == "SangNom2: height must be even."
+    assert validate(Config(width=64, height=34, planes=3, subw=1, subh=1)) == "SangNom2: height must be mod4."
+    assert validate(Config(width=64, height=32, order=3)) == "SangNom2: order must be between 0..2."
+    assert validate(Config(width=64, height=32, aa=200)) == "SangNom2: aa must be between 0..128."
+    assert validate(Config(width=64, height=32, aac=-2)) == "SangNom2: aac must be between 0..128."
+    assert validate(Config(width=64, height=31, order=7)) == "SangNom2: height must be even."  # first check wins
+
+
+def test_chroma_sees_stale_luma_pool():
+    """the nine buffers are luma-sized and shared, so a chroma plane processed after luma
+    differs (slightly) from the same plane processed alone."""
+    cfg = Config(width=128, height=64, planes=3, subw=1, subh=1, aa=48, aac=48)
+    src = synth.frame(cfg, "noise", seed=12)
+    full = Oracle(cfg).process(src)
+    alone = Oracle(Config(width=64, height=32, aa=48)).process([src[1]])
+    assert full[1].shape == alone[0].shape
+    assert not np.array_equal(full[1], alone[0])
+    assert (full[1] != alone[0]).mean() < 0.05
