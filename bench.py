@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SangNom2 hot path on MI355X (contract: see the task statement).
+
+A "step" is one pass of the hot path (frame assembly + the three stages, i.e. everything
+SangNom2::GetFrame does, /root/reference/src/SangNom2.cpp:332-397) over one batch of
+device-resident synthetic frames.  Default workload = the configuration BASELINE.json's metric is
+quoted on: 2160p Y8, order=1, aa=48.  One process per GPU; frames shard across ranks with no
+data-path collective (weak scaling: every rank processes its own batch); torch.distributed (RCCL)
+is used only for the start/stop barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (pixel_type, width, height, filter kwargs)
+    "2160p-Y8": ("Y8", 3840, 2160, dict(order=1, aa=48)),
+    "1080p-Y8": ("Y8", 1920, 1080, dict(order=1, aa=48)),
+    "4320p-Y8": ("Y8", 7680, 4320, dict(order=1, aa=48)),
+    "2160p-YUV420P8": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "2160p-YUV420P16": ("YUV420P16", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
+}
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+
+
+def algorithmic_bytes_per_frame(clip, flt, kw) -> int:
+    """per processed plane read the kept field once and write the whole output plane
+    (1.5 * w * h_out * B); per copied plane 2 * w * h * B.  Scratch buffers count zero."""
+    total = 0
+    for p in range(flt.nplanes):
+        h_out, w = flt.plane_shape_out(p)
+        processed = kw.get("dh", False) or (kw.get("luma", True) if p == 0 else kw.get("chroma", True))
+        total += int((1.5 if processed else 2.0) * w * h_out * clip.bytes)
+    return total
+
+
+def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
+    """The CPU oracle (a scalar port of the reference's opt=0 path) timed on this box's host cores:
+    one context per thread (the reference's MT_MULTI_INSTANCE model), bounded sample."""
+    from avisynth_sangnom2_amd import clip_format, synth
+    from oracle.oracle import Config, Oracle
+
+    clip = clip_format(fmt, w, h)
+    cfg = Config(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subw,
+                 subh=clip.subh, **kw)
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    src = synth.frame(clip, "noise", seed=1)
+    # calibrate on one frame, single thread
+    o = Oracle(cfg)
+    dst = o.process(src)
+    t0 = time.perf_counter()
+    o.process(src, dst=dst)
+    one = time.perf_counter() - t0
+    per_thread = max(1, int(seconds_target / max(one, 1e-3)))
+    per_thread = min(per_thread, 64)
+    oracles = [Oracle(cfg) for _ in range(cores)]
+    dsts = [[d.copy() for d in dst] for _ in range(cores)]
+
+    def work(i):
+        for _ in range(per_thread):
+            oracles[i].process(src, dst=dsts[i])
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    frames = cores * per_thread
+    out_h = h * 2 if kw.get("dh") else h
+    return {"value": round(frames * w * out_h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frames of {fmt} {w}x{h} uniform noise, {cores} threads x {per_thread} frames, "
+                      f"one oracle context per thread ({dt:.1f} s; single-thread {one * 1e3:.0f} ms/frame)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="2160p-Y8", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per step and per GPU (0 = auto)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "pool", "fused"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from avisynth_sangnom2_amd import SangNom2, clip_format
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    fmt, w, h, kw = WORKLOADS[args.workload]
+    clip = clip_format(fmt, w, h)
+    frame_in_bytes = sum((h >> (clip.subh if p else 0)) * (w >> (clip.subw if p else 0)) * clip.bytes
+                         for p in range(min(clip.planes, 3)))
+    # Ring of distinct frames larger than the 256 MiB Infinity Cache (in + out), SURVEY.md 7-H7.
+    batch = args.batch or max(64, min(256, (1 << 30) // frame_in_bytes))
+    stream = torch.cuda.current_stream(dev)
+    flt = SangNom2(clip, device=local_rank, max_batch=batch, mode=args.mode, stream=stream.cuda_stream, **kw)
+    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    src, dst = [], []
+    for p in range(flt.nplanes):
+        hi, wi = flt.plane_shape_in(p)
+        ho, wo = flt.plane_shape_out(p)
+        if clip.bytes == 4:
+            s = torch.rand((batch, hi, wi), device=dev, generator=g, dtype=torch.float32)
+        elif clip.bytes == 2:
+            s = torch.randint(0, 1 << clip.bits, (batch, hi, wi), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+        else:
+            s = torch.randint(0, 256, (batch, hi, wi), device=dev, generator=g, dtype=torch.uint8)
+        src.append(s)
+        dst.append(torch.empty((batch, ho, wo), device=dev, dtype=tdt))
+    out_h = flt.out_height
+    alg_bytes = algorithmic_bytes_per_frame(clip, flt, kw) * batch
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        flt.process_batch(src, dst)
+    torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        flt.process_batch(src, dst)
+        ev[i][1].record(stream)
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch device time of the hot path on the stream it runs on (HIP events)
+    dev_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    launch_ms = sum(dev_ms) / len(dev_ms)
+    info = flt.info()
+
+    if rank == 0:
+        frames_total = batch * args.steps * world
+        mpix = frames_total * w * out_h / elapsed / 1e6
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpixels/s", "value": round(mpix, 1), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": {1: "u8", 2: "u16", 4: "f32"}[clip.bytes],
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload} order={kw.get('order', 1)} aa={kw.get('aa', 48)} "
+                                   f"aac={kw.get('aac', 0)} dh={int(kw.get('dh', False))}, device-resident stream",
+                       "frames_per_step_per_gpu": batch, "frame": f"{w}x{out_h} {fmt}",
+                       "path": "fused" if info.fused_frames > 0 else "pool", "sharding": "frames, no collective"},
+            "frames_per_s": round(frames_total / elapsed, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms_per_launch": round(launch_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fmt, w, h, kw)
+        print(json.dumps(out), flush=True)
+    flt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
