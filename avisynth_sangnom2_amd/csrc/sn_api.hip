@@ -38,8 +38,6 @@ struct Context {
     int stage_src_pitch[3] = {0, 0, 0};
     int stage_dst_pitch[3] = {0, 0, 0};
 
-    FusedPlan* fused = nullptr;
-
     int64_t frames = 0, fused_frames = 0;
     std::string err;
 
@@ -282,6 +280,11 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
         a.offset = offset;
         a.dh = c->cfg.dh;
         a.enabled = (c->cfg.dh || c->process[p]) ? 1 : 0;
+        if (a.enabled && c->use_fused && sn::fused_layout_ok(a)) {
+            SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));
+            if (p == 0 || !(c->cfg.dh || c->process[0])) c->fused_frames += n;
+            continue;
+        }
         SN_HIP(c, sn::launch_assemble(c->stream, a, c->cfg.bytes_per_sample, n));
         if (!a.enabled) continue;
         SN_HIP(c, sn::launch_pool_plane(c->stream, a, c->pool, c->cfg.bytes_per_sample, c->threshold(p), n, 0));
@@ -409,7 +412,3 @@ int sn_debug_read_pool(sn_context* h, int32_t slot, void* host_dst, size_t bytes
 }  // extern "C"
 #pragma GCC visibility pop
 
-namespace sn {
-// Placeholder until sn_fused_u8.hip lands: nothing is eligible, everything takes the pool path.
-bool fused_eligible(const sn_config&) { return false; }
-}  // namespace sn

@@ -42,8 +42,10 @@ hipError_t launch_assemble(hipStream_t s, const PlaneArgs& p, int bytes, int nfr
 hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes,
                              double threshold, int nframes, int slot0);
 
-// sn_fused_u8.hip: fused speculative-tile kernel (8-bit).
-struct FusedPlan;
+// sn_fused_u8.hip: the fused one-pass kernel (8-bit).  launch_fused_u8 also does
+// the plane's frame assembly, so launch_assemble must not be called for a plane it serves.
 bool fused_eligible(const sn_config& c);
+bool fused_layout_ok(const PlaneArgs& p);
+hipError_t launch_fused_u8(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
 
 }  // namespace sn

@@ -122,7 +122,8 @@ def main():
                          for p in range(min(clip.planes, 3)))
     # Ring of distinct frames larger than the 256 MiB Infinity Cache (in + out), SURVEY.md 7-H7.
     batch = args.batch or max(64, min(256, (1 << 30) // frame_in_bytes))
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(dev)  # a real (non-null) HIP stream shared with the context, so that
+    # torch.cuda.Event timing below sees exactly the kernels the library launches
     flt = SangNom2(clip, device=local_rank, max_batch=batch, mode=args.mode, stream=stream.cuda_stream, **kw)
     tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
     g = torch.Generator(device=dev)
@@ -146,6 +147,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    torch.cuda.synchronize(dev)  # inputs were generated on the default stream
     for _ in range(args.warmup):
         flt.process_batch(src, dst)
     torch.cuda.synchronize(dev)

@@ -164,3 +164,70 @@ def test_flat_and_extreme_inputs(hip_lib):
                 src = [np.full((32, 64), v, dtype=clip.dtype)]
                 out = flt.get_frame(src)
                 assert (out[0] == src[0]).all()
+
+
+# ---- the fused 8-bit kernel (sn_fused_u8.hip) ------------------------------------------------------
+
+FUSED_CASES = [
+    # (fmt, w, h, kw): widths chosen to hit 1, 2, 3 and 8 waves per workgroup and mid-wave right edges
+    ("Y8", 32, 8, {}),
+    ("Y8", 512, 20, {}),                 # 64 lanes: one full wave, no ghosts
+    ("Y8", 544, 24, dict(order=2)),      # 68 lanes: 2 waves, second almost empty
+    ("Y8", 992, 26, {}),                 # 124 lanes
+    ("Y8", 1024, 32, dict(aa=100)),      # 128 lanes -> 3 waves
+    ("Y8", 1920, 36, dict(order=0)),
+    ("Y8", 3840, 28, {}),
+    ("Y8", 3968, 16, dict(order=2)),     # widest the fused kernel takes (8 waves)
+    ("Y8", 256, 2, {}),                  # nothing to interpolate
+    ("Y8", 256, 4, dict(order=2)),       # a single interpolated row
+    ("Y8", 256, 6, {}),
+    ("Y8", 640, 40, dict(dh=True)),
+    ("YUV444P8", 576, 24, dict(aac=48)),
+    ("YUV420P8", 576, 24, dict(chroma=False)),  # luma fused, chroma copied
+]
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", FUSED_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in FUSED_CASES])
+@pytest.mark.parametrize("pattern", ["noise", "checker", "edges"])
+def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
+    clip = clip_format(fmt, w, h)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    with SangNom2(clip, mode="fused", **kw) as flt:
+        assert flt.info().fused_eligible == 1
+        for f, src in enumerate(make_frames(clip, pattern, 2, seed0=21)):
+            want = ora.process(src, parity=f & 1)
+            got = flt.get_frame(src, parity=f & 1)
+            for p in range(len(want)):
+                assert same(want[p], got[p]), f"frame {f} plane {p}: " + describe_diff(want[p], got[p])
+        assert flt.info().fused_frames == 2
+
+
+def test_fused_not_eligible_is_reported(hip_lib):
+    for fmt, w, h, kw in (("Y16", 64, 32, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(aac=1)),
+                          ("Y8", 4096, 16, {})):
+        with pytest.raises(SangNomError, match="not eligible"):
+            SangNom2(clip_format(fmt, w, h), mode="fused", **kw)
+
+
+def test_fused_equals_pool_at_full_size(hip_lib):
+    """2160p Y8 (BASELINE.json's metric configuration): the fused kernel and the pool path agree on
+    whole batches of frames, and one frame of the batch is checked against the CPU oracle."""
+    import torch
+    clip = clip_format("Y8", 3840, 2160)
+    N = 3
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    src = [torch.randint(0, 256, (N, 2160, 3840), device=dev, generator=g, dtype=torch.uint8)]
+    src[0][1] = torch.from_numpy(synth.plane(2160, 3840, 1, 8, "checker", 1)).to(dev)
+    outs = {}
+    for mode in ("fused", "pool"):
+        with SangNom2(clip, max_batch=N, mode=mode) as flt:
+            dst = [torch.zeros((N, 2160, 3840), device=dev, dtype=torch.uint8)]
+            torch.cuda.synchronize()
+            flt.process_batch(src, dst, parity=[1, 1, 1])
+            flt.synchronize()
+            outs[mode] = dst[0].cpu().numpy()
+    assert np.array_equal(outs["fused"], outs["pool"])
+    want = Oracle(oracle_cfg(clip)).process([src[0][2].cpu().numpy()])
+    assert same(want[0], outs["fused"][2])
