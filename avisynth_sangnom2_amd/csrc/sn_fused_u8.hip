@@ -23,6 +23,8 @@
 //     is a tenth key with cost aaf + 1 and rank 0 that selects avg(c0, n0).
 //
 // Everything is integer; results are bit-exact to the pool path and to the opt=0 reference.
+#include <type_traits>
+
 #include "sn_internal.h"
 
 namespace sn {
@@ -65,9 +67,12 @@ __device__ __forceinline__ int sad(int a, int b) { return (int)__builtin_amdgcn_
 //   F[j] = sg(p[-1], p[0], p[+1])   B[j] = sg(p[+1], p[0], p[-1])
 // For a pair (c, n): forwardSangNom1 = F(c), forwardSangNom2 = B(n), backwardSangNom1 = B(c),
 // backwardSangNom2 = F(n)  (SangNom2.cpp:100-103).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 struct Line {
-    int p[kTaps];  // p[i] = pixel x0 - 3 + i (edge-clamped)
-    int F[PXL], B[PXL];
+    int p[kTaps];       // p[i] = pixel x0 - 3 + i (edge-clamped)
+    unsigned FB[PXL];   // F | B << 16 (packed to halve the registers a line occupies)
 };
 
 struct Raw {  // a line as loaded: left dword (x0-4..x0-1), own 8 bytes, right dword (x0+8..x0+11)
@@ -107,8 +112,9 @@ __device__ __forceinline__ void unpack(Line& L, const Raw& q)
     for (int j = 0; j < PXL; ++j) {
         const int a = L.p[j + 2], b = L.p[j + 3], c = L.p[j + 4];
         const int x5 = b * 5;
-        L.F[j] = ubfe(4 * a + x5 - c, 3, 8);  // arithmetic >> 3 then wrap to 8 bits == bits 3..10
-        L.B[j] = ubfe(4 * c + x5 - a, 3, 8);
+        const unsigned F = (unsigned)ubfe(4 * a + x5 - c, 3, 8);  // arithmetic >> 3, wrap to 8 bits == bits 3..10
+        const unsigned B = (unsigned)ubfe(4 * c + x5 - a, 3, 8);
+        L.FB[j] = F | (B << 16);
     }
 }
 
@@ -121,9 +127,9 @@ __device__ __forceinline__ int cost(const Line& c, const Line& n, int j)
     if constexpr (BUF == 0) return sad(c.p[i - 3], n.p[i + 3]);  // ADIFF_M3_P3
     if constexpr (BUF == 1) return sad(c.p[i - 2], n.p[i + 2]);  // ADIFF_M2_P2
     if constexpr (BUF == 2) return sad(c.p[i - 1], n.p[i + 1]);  // ADIFF_M1_P1
-    if constexpr (BUF == 3) return sad(c.F[j], n.B[j]);          // SG_FORWARD
+    if constexpr (BUF == 3) return 0;                            // SG_FORWARD: see sg_costs()
     if constexpr (BUF == 4) return sad(c.p[i], n.p[i]);          // ADIFF_P0_M0
-    if constexpr (BUF == 5) return sad(c.B[j], n.F[j]);          // SG_REVERSE
+    if constexpr (BUF == 5) return 0;                            // SG_REVERSE: see sg_costs()
     if constexpr (BUF == 6) return sad(c.p[i + 1], n.p[i - 1]);  // ADIFF_P1_M1
     if constexpr (BUF == 7) return sad(c.p[i + 2], n.p[i - 2]);  // ADIFF_P2_M2
     return sad(c.p[i + 3], n.p[i - 3]);                          // ADIFF_P3_M3
@@ -138,12 +144,27 @@ __device__ __forceinline__ int candidate(const Line& c, const Line& n, int j)
     if constexpr (BUF == 0) return c.p[i - 3] + n.p[i + 3] + ((9 << 12) + 1);
     if constexpr (BUF == 1) return c.p[i - 2] + n.p[i + 2] + ((7 << 12) + 1);
     if constexpr (BUF == 2) return c.p[i - 1] + n.p[i + 1] + ((5 << 12) + 1);
-    if constexpr (BUF == 3) return c.F[j] + n.B[j] + ((3 << 12) + 1);
+    if constexpr (BUF == 3) return (3 << 12) + 1;  // + low half of sg_sums()
     if constexpr (BUF == 4) return c.p[i] + n.p[i] + ((1 << 12) + 1);
-    if constexpr (BUF == 5) return c.B[j] + n.F[j] + ((2 << 12) + 1);
+    if constexpr (BUF == 5) return (2 << 12) + 1;  // + high half of sg_sums()
     if constexpr (BUF == 6) return c.p[i + 1] + n.p[i - 1] + ((4 << 12) + 1);
     if constexpr (BUF == 7) return c.p[i + 2] + n.p[i - 2] + ((6 << 12) + 1);
     return c.p[i + 3] + n.p[i - 3] + ((8 << 12) + 1);
+}
+
+// |F(c) - B(n)| | |B(c) - F(n)| << 16: the SG_FORWARD / SG_REVERSE costs of one pixel, two at a time
+// with packed 16-bit math (op_sel swaps n's halves for free).
+__device__ __forceinline__ unsigned sg_costs(unsigned fb_c, unsigned fb_n)
+{
+    const s16x2 a = __builtin_bit_cast(s16x2, fb_c), b = __builtin_bit_cast(s16x2, fb_n);
+    const s16x2 d = a - __builtin_shufflevector(b, b, 1, 0);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_abs(d));
+}
+// (F(c) + B(n)) | (B(c) + F(n)) << 16: the two SangNom averages' sums.
+__device__ __forceinline__ unsigned sg_sums(unsigned fb_c, unsigned fb_n)
+{
+    const u16x2 a = __builtin_bit_cast(u16x2, fb_c), b = __builtin_bit_cast(u16x2, fb_n);
+    return __builtin_bit_cast(unsigned, a + __builtin_shufflevector(b, b, 1, 0));
 }
 
 struct LaneRole {
@@ -189,51 +210,71 @@ __device__ __forceinline__ void box7(const int (&S)[PXL], int (&Bx)[PXL], const 
 }
 
 // One cost buffer of one row: D[r+1] (or 0 past the last line pair), S, box, O, new A, and the
-// stage-3 key of this buffer folded into the running minimum.
-template <int BUF, bool EDGE, bool HAS_NEXT>
-__device__ __forceinline__ void buffer_step(int (&A)[PXL], unsigned (&kmin)[PXL], const Line& c, const Line& n,
-                                            const Line& nn, const LaneRole& role)
+// stage-3 key of this buffer folded into the running minimum.  A is kept as 16-bit pairs
+// (pixel j | pixel j+4 << 16); d35 / s35 carry the packed SangNom costs / sums of the row.
+template <int BUF, bool HAS_NEXT>
+__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL / 2], unsigned (&kmin)[PXL], const Line& c, const Line& n,
+                                            const Line& nn, const unsigned (&d35)[PXL], const unsigned (&s35)[PXL],
+                                            const LaneRole& role)
 {
     int D[PXL], S[PXL], Bx[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        D[j] = HAS_NEXT ? cost<BUF>(n, nn, j) : 0;
-        S[j] = A[j] + D[j];
+        if constexpr (!HAS_NEXT) D[j] = 0;
+        else if constexpr (BUF == 3) D[j] = (int)(d35[j] & 0xffffu);
+        else if constexpr (BUF == 5) D[j] = (int)(d35[j] >> 16);
+        else D[j] = cost<BUF>(n, nn, j);
     }
-    box7<EDGE>(S, Bx, role);
+#pragma unroll
+    for (int j = 0; j < PXL / 2; ++j) {
+        S[j] = (int)(A[j] & 0xffffu) + D[j];
+        S[j + 4] = (int)(A[j] >> 16) + D[j + 4];
+    }
+    if (role.edge_wave) box7<true>(S, Bx, role);  // wave-uniform branch: only the box differs
+    else box7<false>(S, Bx, role);
+    int O[PXL];
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) O[j] = ubfe(Bx[j], 4, 8);  // (box / 16) mod 256, SangNom2.cpp:152
+#pragma unroll
+    for (int j = 0; j < PXL / 2; ++j) A[j] = (unsigned)(O[j] + D[j]) | ((unsigned)(O[j + 4] + D[j + 4]) << 16);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        const int O = ubfe(Bx[j], 4, 8);  // (box / 16) mod 256, SangNom2.cpp:152
-        A[j] = O + D[j];
-        const unsigned key = ((unsigned)O << 16) | (unsigned)candidate<BUF>(c, n, j);
+        unsigned cand = (unsigned)candidate<BUF>(c, n, j);
+        if constexpr (BUF == 3) cand += s35[j] & 0xffffu;
+        if constexpr (BUF == 5) cand += s35[j] >> 16;
+        const unsigned key = ((unsigned)O[j] << 16) | cand;
         kmin[j] = key < kmin[j] ? key : kmin[j];
     }
 }
 
 }  // namespace
 
-// LDS mailbox: [row parity][wave][side][buffer][3 values + pad]
+// LDS mailbox: [row parity][wave][side][buffer][3 packed A registers + pad]
 struct Mailbox {
-    int v[2][kMaxWaves][2][kBuffers][4];
+    unsigned v[2][kMaxWaves][2][kBuffers][4];
 };
 
-template <bool EDGE, bool HAS_NEXT>
-__device__ __forceinline__ void row_step(int (&A)[kBuffers][PXL], const Line& c, const Line& n, const Line& nn,
+template <bool HAS_NEXT>
+__device__ __forceinline__ void row_step(unsigned (&A)[kBuffers][PXL / 2], const Line& c, const Line& n, const Line& nn,
                                          const LaneRole& role, unsigned thr_key, uint8_t* out_row, int x0, bool real)
 {
-    unsigned kmin[PXL];
+    unsigned kmin[PXL], d35[PXL], s35[PXL];
 #pragma unroll
-    for (int j = 0; j < PXL; ++j)  // the `minBuf > aaf` arm: cost aaf+1, rank 0, value avg(c0, n0)
+    for (int j = 0; j < PXL; ++j) {
+        // the `minBuf > aaf` arm: cost aaf+1, rank 0, value avg(c0, n0)
         kmin[j] = thr_key + (unsigned)(c.p[j + 3] + n.p[j + 3]);
-    buffer_step<0, EDGE, HAS_NEXT>(A[0], kmin, c, n, nn, role);
-    buffer_step<1, EDGE, HAS_NEXT>(A[1], kmin, c, n, nn, role);
-    buffer_step<2, EDGE, HAS_NEXT>(A[2], kmin, c, n, nn, role);
-    buffer_step<3, EDGE, HAS_NEXT>(A[3], kmin, c, n, nn, role);
-    buffer_step<4, EDGE, HAS_NEXT>(A[4], kmin, c, n, nn, role);
-    buffer_step<5, EDGE, HAS_NEXT>(A[5], kmin, c, n, nn, role);
-    buffer_step<6, EDGE, HAS_NEXT>(A[6], kmin, c, n, nn, role);
-    buffer_step<7, EDGE, HAS_NEXT>(A[7], kmin, c, n, nn, role);
-    buffer_step<8, EDGE, HAS_NEXT>(A[8], kmin, c, n, nn, role);
+        d35[j] = HAS_NEXT ? sg_costs(n.FB[j], nn.FB[j]) : 0u;
+        s35[j] = sg_sums(c.FB[j], n.FB[j]);
+    }
+    buffer_step<3, HAS_NEXT>(A[3], kmin, c, n, nn, d35, s35, role);
+    buffer_step<5, HAS_NEXT>(A[5], kmin, c, n, nn, d35, s35, role);
+    buffer_step<0, HAS_NEXT>(A[0], kmin, c, n, nn, d35, s35, role);
+    buffer_step<1, HAS_NEXT>(A[1], kmin, c, n, nn, d35, s35, role);
+    buffer_step<2, HAS_NEXT>(A[2], kmin, c, n, nn, d35, s35, role);
+    buffer_step<4, HAS_NEXT>(A[4], kmin, c, n, nn, d35, s35, role);
+    buffer_step<6, HAS_NEXT>(A[6], kmin, c, n, nn, d35, s35, role);
+    buffer_step<7, HAS_NEXT>(A[7], kmin, c, n, nn, d35, s35, role);
+    buffer_step<8, HAS_NEXT>(A[8], kmin, c, n, nn, d35, s35, role);
     if (real) {
         uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -270,14 +311,16 @@ __global__ void __launch_bounds__(kMaxWaves * 64) k_fused_u8(FusedArgs a)
     LaneRole role;
     role.first_real = gl == 0;
     role.last_real = gl == a.nl - 1;
-    const bool edge_wave = wave == 0 || wave == nw - 1;
+    role.edge_wave = __builtin_amdgcn_readfirstlane(wave == 0 || wave == nw - 1);
 
     const uint8_t* src = a.src + (int64_t)f * a.src_frame_stride;
     uint8_t* dst = a.dst + (int64_t)f * a.dst_frame_stride;
-    auto src_row = [&](int k) { return src + (int64_t)(a.dh ? k : a.offset + 2 * k) * a.src_pitch; };
-    auto dst_row = [&](int k) { return dst + (int64_t)(a.offset + 2 * k) * a.dst_pitch; };
-    auto keep = [&](int k, const Raw& q) {  // GetFrame's field copy, SangNom2.cpp:365 / :376
-        if (real) *reinterpret_cast<uint2*>(dst_row(k) + x0) = make_uint2(q.m0, q.m1);
+    const int64_t src_step = (int64_t)(a.dh ? 1 : 2) * a.src_pitch;  // kept line k -> k + 1 in src
+    const uint8_t* src_line = src + (int64_t)(a.dh ? 0 : a.offset) * a.src_pitch;  // kept line 0
+    const int64_t dst_step = (int64_t)2 * a.dst_pitch;
+    uint8_t* dst_line = dst + (int64_t)a.offset * a.dst_pitch;  // kept line 0 in dst
+    auto keep = [&](uint8_t* row, const Raw& q) {  // GetFrame's field copy, SangNom2.cpp:365 / :376
+        if (real) *reinterpret_cast<uint2*>(row + x0) = make_uint2(q.m0, q.m1);
     };
 
     const int nk = a.nk;
@@ -285,40 +328,53 @@ __global__ void __launch_bounds__(kMaxWaves * 64) k_fused_u8(FusedArgs a)
     const unsigned thr_key = ((unsigned)(a.thr + 1) << 16) + 1u;
 
     Line L0, L1, L2;
-    Raw q0 = load_raw(src_row(0), x0, a.w, live);
-    Raw q1 = nk > 1 ? load_raw(src_row(1), x0, a.w, live) : q0;
-    keep(0, q0);
-    if (a.offset == 1 && real)  // the line that cannot be interpolated, SangNom2.cpp:386-391
-        *reinterpret_cast<uint2*>(dst + x0) = make_uint2(q0.m0, q0.m1);
-    if (nk > 1) keep(1, q1);
+    Raw q0 = load_raw(src_line, x0, a.w, live);
+    Raw q1 = nk > 1 ? load_raw(src_line + src_step, x0, a.w, live) : q0;
+    keep(dst_line, q0);
+    if (a.offset == 1) keep(dst, q0);  // the line that cannot be interpolated, SangNom2.cpp:386-391
+    if (nk > 1) keep(dst_line + dst_step, q1);
     unpack(L0, q0);
     unpack(L1, q1);
 
-    int A[kBuffers][PXL];
     // A[1] = O[0] + D[1] = D[1] (pool row 0 is never written: zero)
+    unsigned A[kBuffers][PXL / 2];
     {
-        int* a0 = A[0]; (void)a0;
+        unsigned d35[PXL];
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) d35[j] = sg_costs(L0.FB[j], L1.FB[j]);
+#define SN_INIT(BUF)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < PXL / 2; ++j)                                                \
+    {                                                                                                  \
+        const unsigned lo = BUF == 3 ? (d35[j] & 0xffffu) : BUF == 5 ? (d35[j] >> 16) : (unsigned)cost<BUF>(L0, L1, j);        \
+        const unsigned hi = BUF == 3 ? (d35[j + 4] & 0xffffu) : BUF == 5 ? (d35[j + 4] >> 16) : (unsigned)cost<BUF>(L0, L1, j + 4); \
+        A[BUF][j] = nr > 0 ? (lo | (hi << 16)) : 0u;                                                   \
     }
-#define SN_INIT(BUF)                                                        \
-    _Pragma("unroll") for (int j = 0; j < PXL; ++j) A[BUF][j] = nr > 0 ? cost<BUF>(L0, L1, j) : 0;
-    SN_INIT(0) SN_INIT(1) SN_INIT(2) SN_INIT(3) SN_INIT(4) SN_INIT(5) SN_INIT(6) SN_INIT(7) SN_INIT(8)
+        SN_INIT(0) SN_INIT(1) SN_INIT(2) SN_INIT(3) SN_INIT(4) SN_INIT(5) SN_INIT(6) SN_INIT(7) SN_INIT(8)
 #undef SN_INIT
+    }
 
-    Raw qn = nk > 2 ? load_raw(src_row(2), x0, a.w, live) : q1;  // line r+1 of the first step
+    // source / destination row cursors: src_next = kept line r+2 at the top of step r
+    const uint8_t* src_next = src_line + 2 * src_step;
+    uint8_t* dst_keep = dst_line + 2 * dst_step;          // where kept line r+1 goes (step r)
+    uint8_t* out_row = dst_line + a.dst_pitch;            // interpolated line of step r
+    Raw qn = nk > 2 ? load_raw(src_next, x0, a.w, live) : q1;  // kept line 2 = line r+1 of step 1
+    src_next += src_step;
 
     // mailbox roles
-    const bool pub_right = real && nw > 1 && wave < nw - 1 && lane == 62;  // feeds next wave's lane 0
-    const bool pub_left = real && wave > 0 && lane == 1;                    // feeds previous wave's lane 63
+    const bool pub_right = real && wave < nw - 1 && lane == 62;  // feeds next wave's lane 0
+    const bool pub_left = real && wave > 0 && lane == 1;         // feeds previous wave's lane 63
     const bool ghost_left = ghost && lane == 0;
     const bool ghost_right = ghost && lane == 63;
 
-    auto step = [&](int r, Line& c, Line& n, Line& nn) {
-        // r = pool row; c = K[r-1], n = K[r], nn = K[r+1]
-        const bool has_next = r < nr;
+    // One pool row r: c = K[r-1], n = K[r], nn = K[r+1].
+    auto step = [&](int r, const Line& c, const Line& n, Line& nn, auto has_next_tag) {
+        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         Raw qnext = qn;
-        if (has_next) {
-            keep(r + 1, qn);
-            if (r + 2 <= nr) qnext = load_raw(src_row(r + 2), x0, a.w, live);  // prefetch K[r+2]
+        if constexpr (HAS_NEXT) {
+            keep(dst_keep, qn);
+            dst_keep += dst_step;
+            if (r + 2 <= nr) qnext = load_raw(src_next, x0, a.w, live);  // prefetch K[r+2]
+            src_next += src_step;
             unpack(nn, qn);
         }
         if (r > 1) {
@@ -327,9 +383,9 @@ __global__ void __launch_bounds__(kMaxWaves * 64) k_fused_u8(FusedArgs a)
             if (ghost_left) {
 #pragma unroll
                 for (int b = 0; b < kBuffers; ++b) {
-                    A[b][5] = mb.v[r & 1][wave][0][b][0];
-                    A[b][6] = mb.v[r & 1][wave][0][b][1];
-                    A[b][7] = mb.v[r & 1][wave][0][b][2];
+                    A[b][1] = mb.v[r & 1][wave][0][b][0];
+                    A[b][2] = mb.v[r & 1][wave][0][b][1];
+                    A[b][3] = mb.v[r & 1][wave][0][b][2];
                 }
             }
             if (ghost_right) {
@@ -341,22 +397,18 @@ __global__ void __launch_bounds__(kMaxWaves * 64) k_fused_u8(FusedArgs a)
                 }
             }
         }
-        uint8_t* out_row = dst + (int64_t)(a.offset + 2 * (r - 1) + 1) * a.dst_pitch;
-        if (edge_wave) {
-            if (has_next) row_step<true, true>(A, c, n, nn, role, thr_key, out_row, x0, real);
-            else row_step<true, false>(A, c, n, nn, role, thr_key, out_row, x0, real);
-        } else {
-            if (has_next) row_step<false, true>(A, c, n, nn, role, thr_key, out_row, x0, real);
-            else row_step<false, false>(A, c, n, nn, role, thr_key, out_row, x0, real);
-        }
-        if (has_next) {
-            // publish A[r+1] of the seam lanes for the neighbouring waves' ghosts
+        row_step<HAS_NEXT>(A, c, n, nn, role, thr_key, out_row, x0, real);
+        out_row += dst_step;
+        if constexpr (HAS_NEXT) {
+            // publish A[r+1] of the seam lanes for the neighbouring waves' ghosts: the left ghost
+            // needs pixels 5..7 (high halves of A[1..3]), the right ghost pixels 0..2 (low halves
+            // of A[0..2]); whole packed registers travel.
             if (pub_right) {
 #pragma unroll
                 for (int b = 0; b < kBuffers; ++b) {
-                    mb.v[(r + 1) & 1][wave + 1][0][b][0] = A[b][5];
-                    mb.v[(r + 1) & 1][wave + 1][0][b][1] = A[b][6];
-                    mb.v[(r + 1) & 1][wave + 1][0][b][2] = A[b][7];
+                    mb.v[(r + 1) & 1][wave + 1][0][b][0] = A[b][1];
+                    mb.v[(r + 1) & 1][wave + 1][0][b][1] = A[b][2];
+                    mb.v[(r + 1) & 1][wave + 1][0][b][2] = A[b][3];
                 }
             }
             if (pub_left) {
@@ -370,17 +422,23 @@ __global__ void __launch_bounds__(kMaxWaves * 64) k_fused_u8(FusedArgs a)
         }
         qn = qnext;
     };
+    using T = std::integral_constant<bool, true>;
+    using F = std::integral_constant<bool, false>;
 
-    for (int r = 1; r <= nr; r += 3) {
-        step(r, L0, L1, L2);
-        if (r + 1 <= nr) step(r + 1, L1, L2, L0);
-        if (r + 2 <= nr) step(r + 2, L2, L0, L1);
+    // rows 1 .. nr-1 have a following line pair; the last row does not (pool row bh is zero).
+    // Lines rotate through register copies: one loop body keeps the code small enough for the
+    // instruction cache (three unrolled rotations did not).
+    for (int r = 1; r < nr; ++r) {
+        step(r, L0, L1, L2, T{});
+        L0 = L1;
+        L1 = L2;
     }
+    if (nr >= 1) step(nr, L0, L1, L2, F{});
 
     // the line that cannot be interpolated when the top field is kept, SangNom2.cpp:380-385:
     // dst row h-1 := dst row h-2 = K[nk-1]
     if (a.offset == 0 && real) {
-        const uint2 m = *reinterpret_cast<const uint2*>(src_row(nk - 1) + x0);
+        const uint2 m = *reinterpret_cast<const uint2*>(src_line + (int64_t)(nk - 1) * src_step + x0);
         *reinterpret_cast<uint2*>(dst + (int64_t)(2 * nk - 1) * a.dst_pitch + x0) = m;
     }
 }
