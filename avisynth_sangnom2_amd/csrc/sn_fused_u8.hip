@@ -50,6 +50,7 @@ struct FusedArgs {
     int32_t thr;     // aaf as integer
     int32_t nl;      // real lanes = w / PXL
     int32_t nw;      // waves per workgroup
+    int32_t dbg;     // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh (wrong results)
 };
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -99,9 +100,10 @@ __device__ __forceinline__ Raw<PXL> load_raw(const uint8_t* row, int x0, int w, 
         } else {
             q.m[0] = *reinterpret_cast<const uint32_t*>(row + x0);
         }
-        q.l = x0 > 0 ? *reinterpret_cast<const uint32_t*>(row + x0 - 4) : (q.m[0] & 0xff) * 0x01010101u;
-        q.r = x0 + PXL < w ? *reinterpret_cast<const uint32_t*>(row + x0 + PXL)
-                           : (q.m[PXL / 4 - 1] >> 24) * 0x01010101u;
+        // the image-edge lanes have no left / right dword: unpack() replicates their edge pixel
+        // (doing it here would make the edge waves wait for the load they have just issued)
+        if (x0 > 0) q.l = *reinterpret_cast<const uint32_t*>(row + x0 - 4);
+        if (x0 + PXL < w) q.r = *reinterpret_cast<const uint32_t*>(row + x0 + PXL);
     }
     return q;
 }
@@ -113,9 +115,19 @@ __device__ __forceinline__ void store_own(uint8_t* row, int x0, const Raw<PXL>& 
     else *reinterpret_cast<uint32_t*>(row + x0) = q.m[0];
 }
 
+struct LaneRole {
+    bool edge_wave;   // wave holds the first or the last real lane: box needs the clamp selects
+    bool first_real;  // lane owns column 0
+    bool last_real;   // lane owns column w - 1
+};
+
 template <int PXL>
-__device__ __forceinline__ void unpack(Line<PXL>& L, const Raw<PXL>& q)
+__device__ __forceinline__ void unpack(Line<PXL>& L, Raw<PXL> q, const LaneRole& role)
 {
+    if (role.edge_wave) {  // loadPixel's clamp (SangNom2.cpp:25-34) for the two image-edge lanes
+        if (role.first_real) q.l = (q.m[0] & 0xff) * 0x01010101u;
+        if (role.last_real) q.r = (q.m[PXL / 4 - 1] >> 24) * 0x01010101u;
+    }
     L.p[0] = ubfe(q.l, 8, 8);
     L.p[1] = ubfe(q.l, 16, 8);
     L.p[2] = (int)(q.l >> 24);
@@ -188,12 +200,6 @@ __device__ __forceinline__ unsigned sg_sums(unsigned fb_c, unsigned fb_n)
     return __builtin_bit_cast(unsigned, a + __builtin_shufflevector(b, b, 1, 0));
 }
 
-struct LaneRole {
-    bool edge_wave;   // wave holds the first or the last real lane: box needs the clamp selects
-    bool first_real;  // lane owns column 0
-    bool last_real;   // lane owns column w - 1
-};
-
 // 7-tap box of S over x (SangNom2.cpp:141-152) for the lane's pixels; the three values on either
 // side come from the neighbouring lanes by DPP.  Sliding window: B[j+1] = B[j] - X[j-3] + X[j+4].
 template <bool EDGE, int PXL>
@@ -258,9 +264,8 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL / 2], unsigned (&k
 }
 
 template <bool HAS_NEXT, int PXL>
-__device__ __forceinline__ void row_step(unsigned (&A)[kBuffers][PXL / 2], const Line<PXL>& c, const Line<PXL>& n,
-                                         const Line<PXL>& nn, const LaneRole& role, unsigned thr_key,
-                                         uint8_t* out_row, int x0, bool real)
+__device__ __forceinline__ Raw<PXL> row_step(unsigned (&A)[kBuffers][PXL / 2], const Line<PXL>& c, const Line<PXL>& n,
+                                             const Line<PXL>& nn, const LaneRole& role, unsigned thr_key)
 {
     unsigned kmin[PXL], d35[PXL], s35[PXL];
 #pragma unroll
@@ -279,23 +284,22 @@ __device__ __forceinline__ void row_step(unsigned (&A)[kBuffers][PXL / 2], const
     buffer_step<6, HAS_NEXT>(A[6], kmin, c, n, nn, d35, s35, role);
     buffer_step<7, HAS_NEXT>(A[7], kmin, c, n, nn, d35, s35, role);
     buffer_step<8, HAS_NEXT>(A[8], kmin, c, n, nn, d35, s35, role);
-    if (real) {
-        Raw<PXL> o;
+    Raw<PXL> o;
+    o.l = o.r = 0;
 #pragma unroll
-        for (int i = 0; i < PXL / 4; ++i) {
-            uint32_t v = 0;
+    for (int i = 0; i < PXL / 4; ++i) {
+        uint32_t v = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v |= (uint32_t)ubfe(kmin[4 * i + j], 1, 8) << (8 * j);  // (a + b + 1) >> 1
-            o.m[i] = v;
-        }
-        store_own<PXL>(out_row, x0, o);
+        for (int j = 0; j < 4; ++j) v |= (uint32_t)ubfe(kmin[4 * i + j], 1, 8) << (8 * j);  // (a + b + 1) >> 1
+        o.m[i] = v;
     }
+    return o;
 }
 
 // Ghost geometry: GH ghost lanes on each inner side of a wave, refresh period K rows.
 template <int PXL>
 struct Seam {
-    static constexpr int GH = PXL == 8 ? 2 : 4;           // ghost lanes per side
+    static constexpr int GH = 2;                          // ghost lanes per side
     static constexpr int K = (GH * PXL) / 3;              // rows between two refreshes (5 for 16 px)
     static constexpr int kFirst = 64 - GH;                // real lanes of wave 0 (no left ghosts)
     static constexpr int kInner = 64 - 2 * GH;            // real lanes of every later wave
@@ -360,8 +364,8 @@ __global__ void __launch_bounds__(PXL == 8 ? 512 : 1024) k_fused_u8(FusedArgs a)
     keep(dst_line, q0);
     if (a.offset == 1) keep(dst, q0);  // the line that cannot be interpolated, SangNom2.cpp:386-391
     if (nk > 1) keep(dst_line + dst_step, q1);
-    unpack(L0, q0);
-    unpack(L1, q1);
+    unpack(L0, q0, role);
+    unpack(L1, q1, role);
 
     // A[1] = O[0] + D[1] = D[1] (pool row 0 is never written: zero)
     unsigned A[kBuffers][H];
@@ -398,19 +402,33 @@ __global__ void __launch_bounds__(PXL == 8 ? 512 : 1024) k_fused_u8(FusedArgs a)
     const bool ghost_right = ghost && lane >= 64 - GH;
     const int slot = ghost_left ? lane : ghost_right ? lane - (64 - GH) : pub_right ? lane - last_real_lane0 : lane - GH;
 
+    // The interpolated line of row r is stored at the top of row r+1, after that row has waited
+    // for its prefetched source line: a store issued at the end of the row would sit between the
+    // prefetch and its wait (vmcnt counts loads and stores in order) and expose its latency.
+    Raw<PXL> pending;
+    pending.l = pending.r = 0;
+#pragma unroll
+    for (int i = 0; i < PXL / 4; ++i) pending.m[i] = 0;
+
     // One pool row r: c = K[r-1], n = K[r], nn = K[r+1].
     auto step = [&](int r, const Line<PXL>& c, const Line<PXL>& n, Line<PXL>& nn, auto has_next_tag) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         Raw<PXL> qnext = qn;
         if constexpr (HAS_NEXT) {
+            unpack(nn, qn, role);  // waits for the line prefetched one row ago
             keep(dst_keep, qn);
             dst_keep += dst_step;
+        }
+        if (r > 1) {
+            keep(out_row, pending);
+            out_row += dst_step;
+        }
+        if constexpr (HAS_NEXT) {
             if (r + 2 <= nr) qnext = load_raw<PXL>(src_next, x0, a.w, live);  // prefetch K[r+2]
             src_next += src_step;
-            unpack(nn, qn);
         }
         const int par = (r / K) & 1;
-        if (r > 1 && (r - 1) % K == 0) {
+        if (r > 1 && (r - 1) % K == 0 && !(a.dbg & 1)) {
             // refresh: the ghosts reload the A state their owners published at the end of row r-1
             __syncthreads();
             if (ghost_left) {
@@ -426,10 +444,9 @@ __global__ void __launch_bounds__(PXL == 8 ? 512 : 1024) k_fused_u8(FusedArgs a)
                     for (int k = 0; k < H; ++k) A[b][k] = mb.v[par][wave][1][slot][b][k];
             }
         }
-        row_step<HAS_NEXT>(A, c, n, nn, role, thr_key, out_row, x0, real);
-        out_row += dst_step;
+        pending = row_step<HAS_NEXT>(A, c, n, nn, role, thr_key);
         if constexpr (HAS_NEXT) {
-            if (r % K == 0) {
+            if (r % K == 0 && !(a.dbg & 1)) {
                 // row r+1 is a refresh row: publish A[r+1] of the seam lanes
                 const int wpar = ((r + 1) / K) & 1;
                 if (pub_right) {
@@ -459,7 +476,10 @@ __global__ void __launch_bounds__(PXL == 8 ? 512 : 1024) k_fused_u8(FusedArgs a)
         L0 = L1;
         L1 = L2;
     }
-    if (nr >= 1) step(nr, L0, L1, L2, F{});
+    if (nr >= 1) {
+        step(nr, L0, L1, L2, F{});
+        keep(out_row, pending);
+    }
 
     // the line that cannot be interpolated when the top field is kept, SangNom2.cpp:380-385:
     // dst row h-1 := dst row h-2 = K[nk-1]
@@ -530,6 +550,8 @@ hipError_t launch_fused_u8(hipStream_t st, const PlaneArgs& p, double threshold,
     const int pxl = choose_pxl(p.w);
     a.nl = p.w / pxl;
     a.nw = waves_for(a.nl, pxl);
+    static const int dbg = [] { const char* e = getenv("SN_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     if (pxl == 8) hipLaunchKernelGGL(k_fused_u8<8>, dim3(nframes), dim3(a.nw * 64), 0, st, a);
     else hipLaunchKernelGGL(k_fused_u8<4>, dim3(nframes), dim3(a.nw * 64), 0, st, a);
     return hipGetLastError();
