@@ -1,0 +1,76 @@
+"""The C++ host-side adapter (host/sangnom2_filter.hpp) driven like a script engine drives the
+reference plugin: SangNom2(clip, order, aa, aac, threads, dh, luma, chroma, opt) then GetFrame(n)
+(/root/reference/src/SangNom2.cpp:399-435, :332-397).  Frames go through pitched host frames, the
+C ABI and the HIP kernels; results are compared with the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from avisynth_sangnom2_amd import clip_format, synth
+from oracle.oracle import Oracle
+from tests.util import oracle_cfg, same
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "host", "sn_host_test")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "sn_host_test"])
+
+
+def _run(tmp_path, clip, kw, frames, parities):
+    _build()
+    hdr = [clip.width, clip.height, clip.bytes, clip.bits, clip.planes, clip.subw, clip.subh,
+           kw.get("order", 1), kw.get("aa", 48), kw.get("aac", 0), int(kw.get("dh", False)),
+           int(kw.get("luma", True)), int(kw.get("chroma", True)), len(frames)]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<14i", *hdr))
+        for fr, par in zip(frames, parities):
+            f.write(struct.pack("<i", par))
+            for pl in fr:
+                f.write(np.ascontiguousarray(pl).tobytes())
+    r = subprocess.run([BIN, fin, fout], capture_output=True, text=True, timeout=300)
+    return r, fout
+
+
+def test_constructor_errors_carry_the_reference_text(tmp_path):
+    """Validation happens before any device is touched, so this runs without a GPU."""
+    for fmt, w, h, kw, text in (
+            ("Y8", 64, 31, {}, "SangNom2: height must be even."),
+            ("YUV420P8", 64, 34, {}, "SangNom2: height must be mod4."),
+            ("Y8", 64, 32, dict(order=5), "SangNom2: order must be between 0..2."),
+            ("Y8", 64, 32, dict(aa=200), "SangNom2: aa must be between 0..128."),
+            ("Y8", 64, 32, dict(aac=129), "SangNom2: aac must be between 0..128.")):
+        r, _ = _run(tmp_path, clip_format(fmt, w, h), kw, [], [])
+        assert r.returncode == 3 and r.stdout.strip() == text, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,w,h,kw", [
+    ("Y8", 256, 64, dict(order=1, aa=48)),
+    ("Y8", 100, 40, dict(order=0, aa=20)),
+    ("YUV420P8", 128, 64, dict(aac=48, order=2)),
+    ("YUV420P16", 96, 32, dict(aac=48)),
+    ("YUV444PS", 64, 24, dict(dh=True, aac=48)),
+    ("YUV420P8", 128, 32, dict(chroma=False)),
+])
+def test_getframe_matches_oracle(tmp_path, fmt, w, h, kw):
+    clip = clip_format(fmt, w, h)
+    frames = [synth.frame(clip, "noise" if i % 2 == 0 else "edges", seed=40 + i) for i in range(3)]
+    parities = [1, 0, 1]
+    r, fout = _run(tmp_path, clip, kw, frames, parities)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    raw = np.fromfile(fout, dtype=np.uint8)
+    pos = 0
+    for f, (fr, par) in enumerate(zip(frames, parities)):
+        want = ora.process(fr, parity=par)
+        for p, wpl in enumerate(want):
+            got = raw[pos:pos + wpl.nbytes].view(wpl.dtype).reshape(wpl.shape)
+            pos += wpl.nbytes
+            assert same(wpl, got), f"{fmt} frame {f} plane {p}"
+    assert pos == raw.size
