@@ -6,6 +6,7 @@
 // of sn_pool_kernels.hip / sn_fused_u8.hip.  There is no CPU fallback in this library.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -281,7 +282,11 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
         a.dh = c->cfg.dh;
         a.enabled = (c->cfg.dh || c->process[p]) ? 1 : 0;
         if (a.enabled && c->use_fused && sn::fused_layout_ok(a)) {
-            SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));
+            static const int ver = [] { const char* e = getenv("SN_FUSED_VER"); return e ? atoi(e) : 2; }();
+            if (ver == 3 && sn::fused_v3_plane_ok(a.w))
+                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n));
+            else
+                SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));
             if (p == 0 || !(c->cfg.dh || c->process[0])) c->fused_frames += n;
             continue;
         }

@@ -1,0 +1,617 @@
+// sn_fused_u8_v3.hip -- fused 8-bit kernel, "two virtual wavefronts per wave" formulation.
+//
+// Same algorithm and the same exactness argument as sn_fused_u8.hip (read its header first):
+// one workgroup sweeps one plane top to bottom, a lane owns 8 consecutive pixels per row, the
+// nine cost buffers live in registers as A[r] = O[r-1] + D[r], ghost lanes make wave seams exact
+// with one barrier every 5 rows.
+//
+// What is new: tools/ubench_valu.hip shows that on gfx950 only plain 32-bit add / sub / and / or /
+// lshr issue at the full VALU rate; v_add3, v_sad, v_bfe, v_lshl_or, v_min, every DPP / SDWA form
+// and every v_pk_* are half rate.  All quantities of stage 1 and 2 fit 13 bits, so every 32-bit
+// register here holds TWO pixels from two different column strips -- bits 0..15 belong to "virtual
+// wavefront" 2W (columns x), bits 16..31 to virtual wavefront 2W+1 (columns x + 480) -- and the
+// pipeline runs on plain full-rate integer ops that process both at once:
+//     S = A + D            one v_add_u32 for two pixels (no carry can cross: sums <= 5355)
+//     box: B[j+1] = B[j] - X[j-3] + X[j+4]   plain adds; window minus a member never borrows
+//     O = (B >> 4) & 0x00ff00ff,  A' = O + D
+//     SangNom value: ((4a + 5b - c + 2048) >> 3) & 0x00ff00ff   (2048 = 8 * 256 keeps it positive
+//                                                                 and does not change the result)
+//     |a - b| = max(a, b) - min(a, b) with v_pk_max_u16 / v_pk_min_u16 and one plain subtract
+// A DPP move of a packed register serves both virtual wavefronts (lane i-1 is the left neighbour
+// in both strips).  Stage 3 finds the winner with 16-bit keys (cost << 4 | rank) and
+// v_pk_min_u16, then selects the winner's tap sum with a 4-level v_bfi tree on rank-bit masks.
+//
+// Reference semantics: /root/reference/src/SangNom2.cpp:74-124, :126-159, :161-257, :361-391.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "sn_internal.h"
+
+namespace sn {
+namespace v3 {
+
+constexpr int PXL = 8;           // pixels per lane and per virtual wavefront
+constexpr int GH = 2;            // ghost lanes on each inner side of a virtual wavefront
+constexpr int K = GH * PXL / 3;  // rows between two seam refreshes (5)
+constexpr int kFirst = 64 - GH;      // real lanes of virtual wavefront 0
+constexpr int kInner = 64 - 2 * GH;  // real lanes of every later virtual wavefront
+constexpr int kMaxWaves = 4;         // physical waves per workgroup (8 virtual wavefronts)
+constexpr unsigned kLo = 0x0000ffffu, kHi = 0xffff0000u, kByte = 0x00ff00ffu;
+
+struct Args {
+    const uint8_t* src;
+    uint8_t* dst;
+    int64_t src_frame_stride;
+    int64_t dst_frame_stride;
+    int32_t src_pitch;
+    int32_t dst_pitch;
+    int32_t w;
+    int32_t nk;      // kept lines
+    int32_t offset;  // first kept line in dst
+    int32_t dh;
+    int32_t thr;
+    int32_t nl;      // real lanes = w / 8
+    int32_t nvw;     // virtual wavefronts
+    int32_t nw;      // physical waves
+    int32_t src_bytes;  // bytes of one source plane (buffer descriptor range)
+    int32_t dst_bytes;  // bytes of one destination plane
+    int32_t dbg;        // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh (wrong results)
+};
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned dpp_from_left(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned dpp_from_right(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// |a - b| in both halves (values < 32768 per half)
+__device__ __forceinline__ unsigned pk_absdiff(unsigned a, unsigned b) { return pk_max(a, b) - pk_min(a, b); }
+// (m & x) | (~m & y): v_bfi_b32
+__device__ __forceinline__ unsigned bfi(unsigned m, unsigned x, unsigned y) { return (m & x) | (~m & y); }
+
+// One kept line: P[i] = pixel (x0 - 3 + i) of both strips, F / B = the two SangNom values per pixel
+// (calculateSangNom, SangNom2.cpp:60-65), all packed lo | hi << 16.
+struct Line {
+    unsigned P[PXL + 6];
+    unsigned FB[PXL];  // F | B << 8 in each 16-bit half (both are 8-bit values)
+    __device__ __forceinline__ unsigned F(int j) const { return FB[j] & kByte; }
+    __device__ __forceinline__ unsigned B(int j) const { return (FB[j] >> 8) & kByte; }
+};
+
+struct RawHalf {  // left dword, own 8 bytes, right dword of one strip
+    uint32_t l, m0, m1, r;
+};
+struct Raw {
+    RawHalf h[2];
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kOutOfRange = 0x7fffffff;  // voffset that the buffer range check always rejects
+
+// One 16-byte buffer load per strip and line: bytes [x0 - 4, x0 + 12) = left dword, own 8 bytes,
+// right dword.  Row base in soffset (wave-uniform), column in voffset; dead lanes carry an
+// out-of-range voffset and read zeros, so there is no branch around memory operations.
+// The lane that owns column 0 loads from column 0 instead (unpack() shifts its dwords).
+__device__ __forceinline__ RawHalf load_half(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return RawHalf{q.x, q.y, q.z, q.w};
+}
+
+struct LaneRole {
+    bool edge_wave;      // wave holds column 0 or column w-1: clamps needed
+    unsigned first_mask; // 0xffff in the half that owns column 0 (else 0)
+    unsigned last_mask;  // 0xffff (shifted) in the half that owns column w-1
+};
+
+// byte k of the lo word -> bits 0..7, byte k of the hi word -> bits 16..23
+__device__ __forceinline__ unsigned pair_byte(uint32_t hi_word, uint32_t lo_word, int k)
+{
+    return __builtin_amdgcn_perm(hi_word, lo_word, 0x0c040c00u + (unsigned)k * 0x00010001u);
+}
+
+__device__ __forceinline__ void unpack(Line& L, Raw q, const LaneRole& role)
+{
+    if (role.edge_wave) {  // loadPixel's clamp (SangNom2.cpp:25-34) for the two image-edge lanes
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (role.first_mask & (h ? kHi : kLo)) {  // loaded from column 0: dwords are one slot early
+                q.h[h].r = q.h[h].m1;
+                q.h[h].m1 = q.h[h].m0;
+                q.h[h].m0 = q.h[h].l;
+                q.h[h].l = (q.h[h].m0 & 0xff) * 0x01010101u;
+            }
+            if (role.last_mask & (h ? kHi : kLo)) q.h[h].r = (q.h[h].m1 >> 24) * 0x01010101u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        L.P[k] = pair_byte(q.h[1].l, q.h[0].l, k + 1);
+        L.P[PXL + 3 + k] = pair_byte(q.h[1].r, q.h[0].r, k);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        L.P[3 + k] = pair_byte(q.h[1].m0, q.h[0].m0, k);
+        L.P[7 + k] = pair_byte(q.h[1].m1, q.h[0].m1, k);
+    }
+    // F = ((4a + 5b - c) >> 3) mod 256, B = ((4c + 5b - a) >> 3) mod 256 with a bias of 2048 per half
+    unsigned Q4[PXL + 2], M[PXL + 2];  // positions 2 .. PXL+3
+#pragma unroll
+    for (int i = 0; i < PXL + 2; ++i) {
+        const unsigned p = L.P[i + 2];
+        const unsigned p2 = p + p;
+        Q4[i] = p2 + p2;
+        M[i] = 0x08000800u - p;
+    }
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        const unsigned q5 = Q4[j + 1] + L.P[j + 3];
+        const unsigned f = ((Q4[j] + q5 + M[j + 2]) >> 3) & kByte;
+        const unsigned b = ((Q4[j + 2] + q5 + M[j]) << 5) & 0xff00ff00u;  // (x >> 3 & 255) << 8
+        L.FB[j] = f | b;
+    }
+}
+
+// Stage 1, buffer BUF, packed position j, pair (c, n); Buffers enum of SangNom2.h:8-20.
+template <int BUF>
+__device__ __forceinline__ unsigned cost(const Line& c, const Line& n, int j)
+{
+    const int i = j + 3;
+    if constexpr (BUF == 0) return pk_absdiff(c.P[i - 3], n.P[i + 3]);
+    if constexpr (BUF == 1) return pk_absdiff(c.P[i - 2], n.P[i + 2]);
+    if constexpr (BUF == 2) return pk_absdiff(c.P[i - 1], n.P[i + 1]);
+    if constexpr (BUF == 3) return pk_absdiff(c.F(j), n.B(j));  // |forwardSangNom1 - forwardSangNom2|
+    if constexpr (BUF == 4) return pk_absdiff(c.P[i], n.P[i]);
+    if constexpr (BUF == 5) return pk_absdiff(c.B(j), n.F(j));  // |backwardSangNom1 - backwardSangNom2|
+    if constexpr (BUF == 6) return pk_absdiff(c.P[i + 1], n.P[i - 1]);
+    if constexpr (BUF == 7) return pk_absdiff(c.P[i + 2], n.P[i - 2]);
+    return pk_absdiff(c.P[i + 3], n.P[i - 3]);
+}
+
+// Stage 3: a + b of the candidate that belongs to buffer BUF (SangNom2.cpp:214-249).
+template <int BUF>
+__device__ __forceinline__ unsigned tap_sum(const Line& c, const Line& n, int j)
+{
+    const int i = j + 3;
+    if constexpr (BUF == 0) return c.P[i - 3] + n.P[i + 3];
+    if constexpr (BUF == 1) return c.P[i - 2] + n.P[i + 2];
+    if constexpr (BUF == 2) return c.P[i - 1] + n.P[i + 1];
+    if constexpr (BUF == 3) return c.F(j) + n.B(j);
+    if constexpr (BUF == 4) return c.P[i] + n.P[i];
+    if constexpr (BUF == 5) return c.B(j) + n.F(j);
+    if constexpr (BUF == 6) return c.P[i + 1] + n.P[i - 1];
+    if constexpr (BUF == 7) return c.P[i + 2] + n.P[i - 2];
+    return c.P[i + 3] + n.P[i - 3];
+}
+
+// rank of buffer BUF in the reference's ladder: P4, P5, P3, P6, P2, P7, P1, P8, P0 -> 1..9
+template <int BUF>
+constexpr unsigned rank_of()
+{
+    constexpr unsigned r[9] = {9, 7, 5, 3, 1, 2, 4, 6, 8};
+    return r[BUF] * 0x00010001u;
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void box7(const unsigned (&S)[PXL], unsigned (&Bx)[PXL], const LaneRole& role)
+{
+    unsigned L[3], R[3];
+    if constexpr (EDGE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            L[k] = bfi(role.first_mask, S[0], dpp_from_left(S[PXL - 3 + k]));        // clamp to column 0
+            R[k] = bfi(role.last_mask, S[PXL - 1], dpp_from_right(S[k]));            // clamp to column w-1
+        }
+    }
+    auto X = [&](int i) -> unsigned {
+        if (i < 0) return EDGE ? L[i + 3] : dpp_from_left(S[PXL + i]);
+        if (i >= PXL) return EDGE ? R[i - PXL] : dpp_from_right(S[i - PXL]);
+        return S[i];
+    };
+    Bx[0] = S[0] + S[1] + S[2] + S[3] + X(-1) + X(-2) + X(-3);
+#pragma unroll
+    for (int j = 0; j + 1 < PXL; ++j) Bx[j + 1] = Bx[j] - X(j - 3) + X(j + 4);
+}
+
+template <int BUF, bool HAS_NEXT>
+__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
+                                            const LaneRole& role)
+{
+    unsigned D[PXL], S[PXL], Bx[PXL];
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        D[j] = HAS_NEXT ? cost<BUF>(n, nn, j) : 0u;
+        S[j] = A[j] + D[j];
+    }
+    if (role.edge_wave) box7<true>(S, Bx, role);
+    else box7<false>(S, Bx, role);
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        A[j] = ((Bx[j] >> 4) & kByte) + D[j];                        // O + D[r+1]
+        kmin[j] = pk_min(kmin[j], (Bx[j] & 0x0ff00ff0u) | rank_of<BUF>());  // (O << 4) | rank
+    }
+}
+
+struct Out {
+    uint32_t lo[2], hi[2];  // 8 interpolated bytes of each strip
+};
+
+// The line above the pair being interpolated (c = K[r-1]) is needed only by stage 3, after the
+// nine buffer steps.  It is parked in LDS while they run (each lane reads back exactly the 24 dwords
+// it wrote itself, so no barrier is involved) -- that keeps the kernel inside 256 VGPRs without
+// scratch spills, whose reloads would park a wave that has only one partner on its SIMD.
+constexpr int kRegBuffers = 6;                      // buffers 0..5 keep their A state in VGPRs,
+constexpr int kLdsBuffers = kBuffers - kRegBuffers;  // buffers 6..8 keep it in LDS between their steps
+struct Parked {
+    uint4 v[6][kMaxWaves * 64];
+    uint4 a[kLdsBuffers][2][kMaxWaves * 64];  // A of the LDS-resident buffers, thread-private slots
+};
+
+__device__ __forceinline__ void load_A(const Parked& pk, int tid, int b, unsigned (&A)[PXL])
+{
+    const uint4 x = pk.a[b - kRegBuffers][0][tid], y = pk.a[b - kRegBuffers][1][tid];
+    A[0] = x.x; A[1] = x.y; A[2] = x.z; A[3] = x.w;
+    A[4] = y.x; A[5] = y.y; A[6] = y.z; A[7] = y.w;
+}
+__device__ __forceinline__ void store_A(Parked& pk, int tid, int b, const unsigned (&A)[PXL])
+{
+    pk.a[b - kRegBuffers][0][tid] = make_uint4(A[0], A[1], A[2], A[3]);
+    pk.a[b - kRegBuffers][1][tid] = make_uint4(A[4], A[5], A[6], A[7]);
+}
+
+__device__ __forceinline__ void park_line(Parked& pk, int tid, const Line& L)
+{
+    pk.v[0][tid] = make_uint4(L.P[0], L.P[1], L.P[2], L.P[3]);
+    pk.v[1][tid] = make_uint4(L.P[4], L.P[5], L.P[6], L.P[7]);
+    pk.v[2][tid] = make_uint4(L.P[8], L.P[9], L.P[10], L.P[11]);
+    pk.v[3][tid] = make_uint4(L.P[12], L.P[13], L.FB[0], L.FB[1]);
+    pk.v[4][tid] = make_uint4(L.FB[2], L.FB[3], L.FB[4], L.FB[5]);
+    pk.v[5][tid] = make_uint4(L.FB[6], L.FB[7], 0u, 0u);
+}
+
+__device__ __forceinline__ void unpark_line(const Parked& pk, int tid, Line& L)
+{
+    const uint4 a = pk.v[0][tid], b = pk.v[1][tid], c = pk.v[2][tid], d = pk.v[3][tid], e = pk.v[4][tid], f = pk.v[5][tid];
+    L.P[0] = a.x; L.P[1] = a.y; L.P[2] = a.z; L.P[3] = a.w;
+    L.P[4] = b.x; L.P[5] = b.y; L.P[6] = b.z; L.P[7] = b.w;
+    L.P[8] = c.x; L.P[9] = c.y; L.P[10] = c.z; L.P[11] = c.w;
+    L.P[12] = d.x; L.P[13] = d.y; L.FB[0] = d.z; L.FB[1] = d.w;
+    L.FB[2] = e.x; L.FB[3] = e.y; L.FB[4] = e.z; L.FB[5] = e.w;
+    L.FB[6] = f.x; L.FB[7] = f.y;
+}
+
+template <bool HAS_NEXT>
+__device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], Parked& pk, int tid, const Line& n,
+                                        const Line& nn, const LaneRole& role, unsigned thr_key)
+{
+    unsigned kmin[PXL];
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
+    auto in_regs = [&](auto buf) {
+        constexpr int B = decltype(buf)::value;
+        buffer_step<B, HAS_NEXT>(A[B], kmin, n, nn, role);
+    };
+    auto in_lds = [&](auto buf) {
+        constexpr int B = decltype(buf)::value;
+        unsigned t[PXL];
+        load_A(pk, tid, B, t);
+        buffer_step<B, HAS_NEXT>(t, kmin, n, nn, role);
+        store_A(pk, tid, B, t);
+    };
+    auto run = [&](auto buf) {
+        if constexpr (decltype(buf)::value < kRegBuffers) in_regs(buf);
+        else in_lds(buf);
+    };
+    run(std::integral_constant<int, 0>{});
+    run(std::integral_constant<int, 1>{});
+    run(std::integral_constant<int, 2>{});
+    run(std::integral_constant<int, 3>{});
+    run(std::integral_constant<int, 4>{});
+    run(std::integral_constant<int, 5>{});
+    run(std::integral_constant<int, 6>{});
+    run(std::integral_constant<int, 7>{});
+    run(std::integral_constant<int, 8>{});
+
+    // winner's rank -> tap sum -> average
+    Line c;
+    unpark_line(pk, tid, c);
+    unsigned v[PXL];
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        const unsigned wk = kmin[j];
+        const unsigned m0 = (wk & 0x00010001u) * 0xffffu;
+        const unsigned m1 = ((wk >> 1) & 0x00010001u) * 0xffffu;
+        const unsigned m2 = ((wk >> 2) & 0x00010001u) * 0xffffu;
+        const unsigned m3 = ((wk >> 3) & 0x00010001u) * 0xffffu;
+        // ranks: 0,1 -> P4; 2 -> P5; 3 -> P3; 4 -> P6; 5 -> P2; 6 -> P7; 7 -> P1; 8 -> P8; 9 -> P0
+        const unsigned a01 = tap_sum<4>(c, n, j);
+        const unsigned a23 = bfi(m0, tap_sum<3>(c, n, j), tap_sum<5>(c, n, j));
+        const unsigned a45 = bfi(m0, tap_sum<2>(c, n, j), tap_sum<6>(c, n, j));
+        const unsigned a67 = bfi(m0, tap_sum<1>(c, n, j), tap_sum<7>(c, n, j));
+        const unsigned a89 = bfi(m0, tap_sum<0>(c, n, j), tap_sum<8>(c, n, j));
+        const unsigned b0 = bfi(m1, a23, a01);
+        const unsigned b1 = bfi(m1, a67, a45);
+        const unsigned c0 = bfi(m2, b1, b0);
+        const unsigned r = bfi(m3, a89, c0);
+        v[j] = ((r + 0x00010001u) >> 1) & kByte;  // (a + b + 1) >> 1
+    }
+    // v[j] = lo-strip byte | hi-strip byte << 16  ->  four bytes per dword and strip
+    Out o;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const unsigned t01 = __builtin_amdgcn_perm(v[4 * g + 1], v[4 * g + 0], 0x06020400u);  // [v0.b0, v1.b0, v0.b2, v1.b2]
+        const unsigned t23 = __builtin_amdgcn_perm(v[4 * g + 3], v[4 * g + 2], 0x06020400u);
+        o.lo[g] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);  // [t01.b0, t01.b1, t23.b0, t23.b1]
+        o.hi[g] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);  // [t01.b2, t01.b3, t23.b2, t23.b3]
+    }
+    return o;
+}
+
+// LDS mailbox, receiver-ready: word [refresh parity][wave W][side][slot][i] is what ghost lane
+// `slot` on that side of wave W loads into packed A register i -- its low half written by one
+// publisher, its high half by another (16-bit LDS stores), so receiving costs no shuffling:
+//   left ghosts  (lanes 0, 1)   of wave W: lo <- wave W-1 lanes 60, 61 hi half; hi <- wave W lanes 60, 61 lo half
+//   right ghosts (lanes 62, 63) of wave W: lo <- wave W lanes 2, 3 hi half;     hi <- wave W+1 lanes 2, 3 lo half
+struct Mailbox {
+    unsigned short h[2][kMaxWaves + 1][2][GH][kBuffers * PXL][2];
+};
+
+__global__ void __launch_bounds__(kMaxWaves * 64, 2) k_fused_u8_v3(Args a)
+{
+    __shared__ Mailbox mb;
+    __shared__ Parked parked;
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int nvw = a.nvw;
+
+    // per-half lane roles: virtual wavefront vw = 2 * wave + half
+    int x0[2];
+    bool live[2], real[2], ghost[2];
+    LaneRole role;
+    role.first_mask = 0;
+    role.last_mask = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int vw = 2 * wave + h;
+        int gl;
+        bool g;
+        if (vw == 0) {
+            gl = lane;
+            g = (nvw > 1) && lane >= 64 - GH;
+        } else {
+            gl = kFirst + kInner * (vw - 1) + (lane - GH);
+            g = lane < GH || (lane >= 64 - GH && vw < nvw - 1);
+        }
+        live[h] = vw < nvw && gl < a.nl;
+        ghost[h] = g;
+        real[h] = live[h] && !g;
+        x0[h] = gl * PXL;
+        if (live[h] && gl == 0) role.first_mask |= h ? kHi : kLo;
+        if (live[h] && gl == a.nl - 1) role.last_mask |= h ? kHi : kLo;
+    }
+    role.edge_wave = __builtin_amdgcn_readfirstlane(__any((int)(role.first_mask | role.last_mask)) ? 1 : 0) != 0;
+
+    // Buffer descriptors of this frame's source / destination plane; rows are addressed through the
+    // scalar offset, columns through per-lane voffsets that never change.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.src + (int64_t)f * a.src_frame_stride), 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd =
+        __builtin_amdgcn_make_buffer_rsrc(a.dst + (int64_t)f * a.dst_frame_stride, 0, a.dst_bytes, 0x00020000);
+    int vload[2], vstore[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        vload[h] = live[h] ? (x0[h] > 0 ? x0[h] - 4 : 0) : kOutOfRange;
+        vstore[h] = real[h] ? x0[h] : kOutOfRange;
+    }
+    const int src_step = (a.dh ? 1 : 2) * a.src_pitch;        // kept line k -> k + 1
+    const int src_line = (a.dh ? 0 : a.offset) * a.src_pitch;  // kept line 0
+    const int dst_step = 2 * a.dst_pitch;
+    const int dst_line = a.offset * a.dst_pitch;  // kept line 0 in dst
+
+    auto load_raw = [&](int row_off) {
+        Raw q;
+        q.h[0] = load_half(rs, vload[0], row_off);
+        q.h[1] = load_half(rs, vload[1], row_off);
+        return q;
+    };
+    auto own = [&](const Raw& q, int h) {  // the 8 bytes the lane owns (the column-0 lane loaded them first)
+        const bool first = (role.first_mask & (h ? kHi : kLo)) != 0;
+        u32x2 v;
+        v.x = first ? q.h[h].l : q.h[h].m0;
+        v.y = first ? q.h[h].m0 : q.h[h].m1;
+        return v;
+    };
+    auto keep = [&](int row_off, const Raw& q) {  // GetFrame's field copy, SangNom2.cpp:365 / :376
+        __builtin_amdgcn_raw_buffer_store_b64(own(q, 0), rd, vstore[0], row_off, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(own(q, 1), rd, vstore[1], row_off, 0);
+    };
+    auto put = [&](int row_off, const Out& o) {
+        u32x2 lo, hi;
+        lo.x = o.lo[0]; lo.y = o.lo[1];
+        hi.x = o.hi[0]; hi.y = o.hi[1];
+        __builtin_amdgcn_raw_buffer_store_b64(lo, rd, vstore[0], row_off, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(hi, rd, vstore[1], row_off, 0);
+    };
+
+    const int nk = a.nk;
+    const int nr = nk - 1;
+    const unsigned thr_key = (unsigned)((a.thr + 1) << 4) * 0x00010001u;
+
+    Line L0, L1;
+    Raw q0 = load_raw(src_line);
+    Raw q1 = nk > 1 ? load_raw(src_line + src_step) : q0;
+    keep(dst_line, q0);
+    if (a.offset == 1) keep(0, q0);  // the line that cannot be interpolated, SangNom2.cpp:386-391
+    if (nk > 1) keep(dst_line + dst_step, q1);
+    unpack(L0, q0, role);
+    unpack(L1, q1, role);
+    park_line(parked, tid, L0);  // c of row 1
+
+    // A[1] = O[0] + D[1] = D[1] (pool row 0 is never written: zero)
+    unsigned A[kRegBuffers][PXL];
+#define SN_INIT(BUF) _Pragma("unroll") for (int j = 0; j < PXL; ++j) A[BUF][j] = nr > 0 ? cost<BUF>(L0, L1, j) : 0u;
+    SN_INIT(0) SN_INIT(1) SN_INIT(2) SN_INIT(3) SN_INIT(4) SN_INIT(5)
+#undef SN_INIT
+#define SN_INIT_LDS(BUF)                                                                 \
+    {                                                                                    \
+        unsigned t[PXL];                                                                 \
+        _Pragma("unroll") for (int j = 0; j < PXL; ++j) t[j] = nr > 0 ? cost<BUF>(L0, L1, j) : 0u; \
+        store_A(parked, tid, BUF, t);                                                    \
+    }
+    SN_INIT_LDS(6) SN_INIT_LDS(7) SN_INIT_LDS(8)
+#undef SN_INIT_LDS
+
+    int src_next = src_line + 2 * src_step;
+    int dst_keep = dst_line + 2 * dst_step;
+    int out_row = dst_line + a.dst_pitch;
+    Raw qn = nk > 2 ? load_raw(src_next) : q1;
+    src_next += src_step;
+
+    // Seam exchange roles.  Lanes 60, 61 are the right seam lanes and lanes 2, 3 the left seam
+    // lanes of BOTH virtual wavefronts of this wave, so they publish whole packed registers; the
+    // ghost lanes (0, 1 and 62, 63) take one half from each of two published registers.
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH;
+    const bool pub_left = lane >= GH && lane < 2 * GH;
+    const bool recv_left = lane < GH;        // left ghosts of vw 2W (from wave W-1, hi) and 2W+1 (from wave W, lo)
+    const bool recv_right = lane >= 64 - GH; // right ghosts of vw 2W (from wave W, hi) and 2W+1 (from wave W+1, lo)
+    const unsigned ghost_mask = (ghost[0] && live[0] ? kLo : 0u) | (ghost[1] && live[1] ? kHi : 0u);
+    const int slot = recv_left ? lane : recv_right ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    Out pending{};
+    auto step = [&](int r, Line& n, Line& nn, auto has_next_tag) {
+        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+        Raw qnext = qn;
+        if constexpr (HAS_NEXT) {
+            unpack(nn, qn, role);  // waits for the line prefetched one row ago
+            keep(dst_keep, qn);
+            dst_keep += dst_step;
+        }
+        if (r > 1) {
+            put(out_row, pending);
+            out_row += dst_step;
+        }
+        if constexpr (HAS_NEXT) {
+            if (r + 2 <= nr) qnext = load_raw(src_next);  // prefetch K[r+2]
+            src_next += src_step;
+        }
+        const int par = (r / K) & 1;
+        if (r > 1 && (r - 1) % K == 0 && !(a.dbg & 1)) {
+            __syncthreads();
+            if (recv_left || recv_right) {
+                const unsigned* from = reinterpret_cast<const unsigned*>(&mb.h[par][wave][recv_left ? 0 : 1][slot][0][0]);
+                auto merge = [&](int b, unsigned (&Ab)[PXL]) {
+#pragma unroll
+                    for (int j = 0; j < PXL; ++j) Ab[j] = bfi(ghost_mask, from[b * PXL + j], Ab[j]);
+                };
+#pragma unroll
+                for (int b = 0; b < kRegBuffers; ++b) merge(b, A[b]);
+#pragma unroll
+                for (int b = kRegBuffers; b < kBuffers; ++b) {
+                    unsigned t[PXL];
+                    load_A(parked, tid, b, t);
+                    merge(b, t);
+                    store_A(parked, tid, b, t);
+                }
+            }
+        }
+        pending = row_step<HAS_NEXT>(A, parked, tid, n, nn, role, thr_key);
+        if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
+        if constexpr (HAS_NEXT) {
+            if (r % K == 0 && !(a.dbg & 1)) {
+                const int wpar = ((r + 1) / K) & 1;
+                if (pub_right || pub_left) {
+                    // my lo half feeds the ghost's hi half and vice versa (see Mailbox)
+                    unsigned short(*to_hi)[2] = pub_right ? mb.h[wpar][wave][0][slot] : mb.h[wpar][wave > 0 ? wave - 1 : kMaxWaves][1][slot];
+                    unsigned short(*to_lo)[2] = pub_right ? mb.h[wpar][wave + 1][0][slot] : mb.h[wpar][wave][1][slot];
+                    auto send = [&](int b, const unsigned (&Ab)[PXL]) {
+#pragma unroll
+                        for (int j = 0; j < PXL; ++j) {
+                            to_hi[b * PXL + j][1] = (unsigned short)(Ab[j] & 0xffffu);
+                            to_lo[b * PXL + j][0] = (unsigned short)(Ab[j] >> 16);
+                        }
+                    };
+#pragma unroll
+                    for (int b = 0; b < kRegBuffers; ++b) send(b, A[b]);
+#pragma unroll
+                    for (int b = kRegBuffers; b < kBuffers; ++b) {
+                        unsigned t[PXL];
+                        load_A(parked, tid, b, t);
+                        send(b, t);
+                    }
+                }
+            }
+        }
+        qn = qnext;
+    };
+    using T = std::integral_constant<bool, true>;
+    using F = std::integral_constant<bool, false>;
+
+    // L1 = K[r] (n), L0 is reused for K[r+1] (nn); c lives in LDS
+    for (int r = 1; r < nr; ++r) {
+        step(r, L1, L0, T{});
+        L1 = L0;
+    }
+    if (nr >= 1) {
+        step(nr, L1, L0, F{});
+        put(out_row, pending);
+    }
+
+    // dst row h-1 := K[nk-1] when the top field is kept, SangNom2.cpp:380-385
+    if (a.offset == 0) {
+        const Raw q = load_raw(src_line + (nk - 1) * src_step);
+        keep((2 * nk - 1) * a.dst_pitch, q);
+    }
+}
+
+static int virtual_waves_for(int nl) { return nl <= 64 ? 1 : 1 + (nl - kFirst + kInner - 1) / kInner; }
+
+}  // namespace v3
+
+bool fused_v3_plane_ok(int w)
+{
+    if (w % 32 != 0) return false;
+    return v3::virtual_waves_for(w / v3::PXL) <= 2 * v3::kMaxWaves;
+}
+
+hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes)
+{
+    v3::Args a{};
+    a.src = p.src;
+    a.dst = p.dst;
+    a.src_frame_stride = p.src_frame_stride;
+    a.dst_frame_stride = p.dst_frame_stride;
+    a.src_pitch = p.src_pitch;
+    a.dst_pitch = p.dst_pitch;
+    a.w = p.w;
+    a.nk = p.h_out / 2;
+    a.offset = p.offset;
+    a.dh = p.dh;
+    a.thr = (int)threshold;
+    a.nl = p.w / v3::PXL;
+    a.nvw = v3::virtual_waves_for(a.nl);
+    a.nw = (a.nvw + 1) / 2;
+    a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
+    a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
+    static const int dbg = [] { const char* e = getenv("SN_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    hipLaunchKernelGGL(v3::k_fused_u8_v3, dim3(nframes), dim3(a.nw * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace sn

@@ -47,5 +47,8 @@ hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& 
 bool fused_eligible(const sn_config& c);
 bool fused_layout_ok(const PlaneArgs& p);
 hipError_t launch_fused_u8(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
+// sn_fused_u8_v3.hip: the same sweep with two virtual wavefronts packed into every register.
+bool fused_v3_plane_ok(int w);
+hipError_t launch_fused_u8_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
 
 }  // namespace sn
