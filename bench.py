@@ -121,8 +121,8 @@ def main():
     frame_in_bytes = sum((h >> (clip.subh if p else 0)) * (w >> (clip.subw if p else 0)) * clip.bytes
                          for p in range(min(clip.planes, 3)))
     # Ring of distinct frames larger than the 256 MiB Infinity Cache (in + out), SURVEY.md 7-H7.
-    # One fused-kernel workgroup sweeps one plane, so a batch of >= 256 frames (one per CU) fills the chip.
-    batch = args.batch or max(64, min(256, (3 << 30) // frame_in_bytes))
+    # One fused-kernel workgroup (4 waves) sweeps one plane and two fit a CU, so 512 frames fill the chip.
+    batch = args.batch or max(64, min(512, (6 << 30) // frame_in_bytes))
     stream = torch.cuda.Stream(dev)  # a real (non-null) HIP stream shared with the context, so that
     # torch.cuda.Event timing below sees exactly the kernels the library launches
     flt = SangNom2(clip, device=local_rank, max_batch=batch, mode=args.mode, stream=stream.cuda_stream, **kw)
