@@ -47,6 +47,26 @@ def algorithmic_bytes_per_frame(clip, flt, kw) -> int:
     return total
 
 
+def recorded_traffic(workload: str, batch: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.csv:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 coalesced reads).  Only valid for the configuration the
+    passes were run on; None otherwise (the counters cannot be read from inside this process)."""
+    if workload != "2160p-Y8" or batch != 512:
+        return None
+    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    vals = {}
+    for row in csv.DictReader(open(path)):
+        if row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[row["counter"]] = float(row["sum_over_dims"])  # last dispatch wins
+    if len(vals) != 2:
+        return None
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+
+
 def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
     """The CPU oracle (a scalar port of the reference's opt=0 path) timed on this box's host cores:
     one context per thread (the reference's MT_MULTI_INSTANCE model), bounded sample."""
@@ -190,7 +210,7 @@ def main():
                        "path": "fused" if info.fused_frames > 0 else "pool", "sharding": "frames, no collective"},
             "frames_per_s": round(frames_total / elapsed, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(args.workload, batch),
                          "kernel_ms_per_launch": round(launch_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
