@@ -284,7 +284,7 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
         if (a.enabled && c->use_fused && sn::fused_layout_ok(a)) {
             // SN_FUSED_VER=2 selects the previous formulation (sn_fused_u8.hip) for A/B runs
             static const int ver = [] { const char* e = getenv("SN_FUSED_VER"); return e ? atoi(e) : 3; }();
-            if (ver == 3 && sn::fused_v3_plane_ok(a.w))
+            if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w))
                 SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n));
             else
                 SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));

@@ -513,9 +513,9 @@ int choose_pxl(int w)
 
 // ---- host side -------------------------------------------------------------------------------
 
-bool fused_plane_ok(int w, int bytes)
+bool fused_v2_plane_ok(int w)
 {
-    if (bytes != 1 || w % 32 != 0) return false;
+    if (w % 32 != 0) return false;
     return waves_for(w / 4, 4) <= 16 || waves_for(w / 8, 8) <= 8;
 }
 
@@ -524,7 +524,7 @@ bool fused_plane_ok(int w, int bytes)
 bool fused_eligible(const sn_config& c)
 {
     if (c.bytes_per_sample != 1) return false;
-    if (!fused_plane_ok(c.width, 1)) return false;
+    if (!fused_v3_plane_ok(c.width) && !fused_v2_plane_ok(c.width)) return false;
     const int np = c.num_planes < 3 ? c.num_planes : 3;
     for (int p = 1; p < np; ++p) {
         const bool processed = c.dh || c.chroma;

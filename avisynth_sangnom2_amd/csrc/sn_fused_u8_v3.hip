@@ -36,7 +36,7 @@ constexpr int GH = 2;            // ghost lanes on each inner side of a virtual 
 constexpr int K = GH * PXL / 3;  // rows between two seam refreshes (5)
 constexpr int kFirst = 64 - GH;      // real lanes of virtual wavefront 0
 constexpr int kInner = 64 - 2 * GH;  // real lanes of every later virtual wavefront
-constexpr int kMaxWaves = 4;         // physical waves per workgroup (8 virtual wavefronts)
+constexpr int kMaxWaves = 8;         // physical waves per workgroup (16 virtual wavefronts, 7680 pixels)
 constexpr unsigned kLo = 0x0000ffffu, kHi = 0xffff0000u, kByte = 0x00ff00ffu;
 
 struct Args {
@@ -256,36 +256,42 @@ struct Out {
 // scratch spills, whose reloads would park a wave that has only one partner on its SIMD.
 constexpr int kRegBuffers = 6;                      // buffers 0..5 keep their A state in VGPRs,
 constexpr int kLdsBuffers = kBuffers - kRegBuffers;  // buffers 6..8 keep it in LDS between their steps
-struct Parked {
-    uint4 v[6][kMaxWaves * 64];
-    uint4 a[kLdsBuffers][2][kMaxWaves * 64];  // A of the LDS-resident buffers, thread-private slots
+template <int NT>
+struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
+    static constexpr int nthreads = NT;
+    uint4* v;    // [6][NT]: the parked line
+    uint4* a;    // [kLdsBuffers][2][NT]: A of the LDS-resident buffers, thread-private slots
 };
 
-__device__ __forceinline__ void load_A(const Parked& pk, int tid, int b, unsigned (&A)[PXL])
+template <int NT>
+__device__ __forceinline__ void load_A(const Parked<NT>& pk, int tid, int b, unsigned (&A)[PXL])
 {
-    const uint4 x = pk.a[b - kRegBuffers][0][tid], y = pk.a[b - kRegBuffers][1][tid];
+    const uint4 x = pk.a[((b - kRegBuffers) * 2 + 0) * pk.nthreads + tid], y = pk.a[((b - kRegBuffers) * 2 + 1) * pk.nthreads + tid];
     A[0] = x.x; A[1] = x.y; A[2] = x.z; A[3] = x.w;
     A[4] = y.x; A[5] = y.y; A[6] = y.z; A[7] = y.w;
 }
-__device__ __forceinline__ void store_A(Parked& pk, int tid, int b, const unsigned (&A)[PXL])
+template <int NT>
+__device__ __forceinline__ void store_A(const Parked<NT>& pk, int tid, int b, const unsigned (&A)[PXL])
 {
-    pk.a[b - kRegBuffers][0][tid] = make_uint4(A[0], A[1], A[2], A[3]);
-    pk.a[b - kRegBuffers][1][tid] = make_uint4(A[4], A[5], A[6], A[7]);
+    pk.a[((b - kRegBuffers) * 2 + 0) * pk.nthreads + tid] = make_uint4(A[0], A[1], A[2], A[3]);
+    pk.a[((b - kRegBuffers) * 2 + 1) * pk.nthreads + tid] = make_uint4(A[4], A[5], A[6], A[7]);
 }
 
-__device__ __forceinline__ void park_line(Parked& pk, int tid, const Line& L)
+template <int NT>
+__device__ __forceinline__ void park_line(const Parked<NT>& pk, int tid, const Line& L)
 {
-    pk.v[0][tid] = make_uint4(L.P[0], L.P[1], L.P[2], L.P[3]);
-    pk.v[1][tid] = make_uint4(L.P[4], L.P[5], L.P[6], L.P[7]);
-    pk.v[2][tid] = make_uint4(L.P[8], L.P[9], L.P[10], L.P[11]);
-    pk.v[3][tid] = make_uint4(L.P[12], L.P[13], L.FB[0], L.FB[1]);
-    pk.v[4][tid] = make_uint4(L.FB[2], L.FB[3], L.FB[4], L.FB[5]);
-    pk.v[5][tid] = make_uint4(L.FB[6], L.FB[7], 0u, 0u);
+    pk.v[0 * pk.nthreads + tid] = make_uint4(L.P[0], L.P[1], L.P[2], L.P[3]);
+    pk.v[1 * pk.nthreads + tid] = make_uint4(L.P[4], L.P[5], L.P[6], L.P[7]);
+    pk.v[2 * pk.nthreads + tid] = make_uint4(L.P[8], L.P[9], L.P[10], L.P[11]);
+    pk.v[3 * pk.nthreads + tid] = make_uint4(L.P[12], L.P[13], L.FB[0], L.FB[1]);
+    pk.v[4 * pk.nthreads + tid] = make_uint4(L.FB[2], L.FB[3], L.FB[4], L.FB[5]);
+    pk.v[5 * pk.nthreads + tid] = make_uint4(L.FB[6], L.FB[7], 0u, 0u);
 }
 
-__device__ __forceinline__ void unpark_line(const Parked& pk, int tid, Line& L)
+template <int NT>
+__device__ __forceinline__ void unpark_line(const Parked<NT>& pk, int tid, Line& L)
 {
-    const uint4 a = pk.v[0][tid], b = pk.v[1][tid], c = pk.v[2][tid], d = pk.v[3][tid], e = pk.v[4][tid], f = pk.v[5][tid];
+    const uint4 a = pk.v[0 * pk.nthreads + tid], b = pk.v[1 * pk.nthreads + tid], c = pk.v[2 * pk.nthreads + tid], d = pk.v[3 * pk.nthreads + tid], e = pk.v[4 * pk.nthreads + tid], f = pk.v[5 * pk.nthreads + tid];
     L.P[0] = a.x; L.P[1] = a.y; L.P[2] = a.z; L.P[3] = a.w;
     L.P[4] = b.x; L.P[5] = b.y; L.P[6] = b.z; L.P[7] = b.w;
     L.P[8] = c.x; L.P[9] = c.y; L.P[10] = c.z; L.P[11] = c.w;
@@ -294,8 +300,8 @@ __device__ __forceinline__ void unpark_line(const Parked& pk, int tid, Line& L)
     L.FB[6] = f.x; L.FB[7] = f.y;
 }
 
-template <bool HAS_NEXT>
-__device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], Parked& pk, int tid, const Line& n,
+template <bool HAS_NEXT, int NT>
+__device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], const Parked<NT>& pk, int tid, const Line& n,
                                         const Line& nn, const LaneRole& role, unsigned thr_key)
 {
     unsigned kmin[PXL];
@@ -366,16 +372,31 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], Parked&
 // publisher, its high half by another (16-bit LDS stores), so receiving costs no shuffling:
 //   left ghosts  (lanes 0, 1)   of wave W: lo <- wave W-1 lanes 60, 61 hi half; hi <- wave W lanes 60, 61 lo half
 //   right ghosts (lanes 62, 63) of wave W: lo <- wave W lanes 2, 3 hi half;     hi <- wave W+1 lanes 2, 3 lo half
-struct Mailbox {
-    unsigned short h[2][kMaxWaves + 1][2][GH][kBuffers * PXL][2];
+template <int NW>
+struct Mailbox {  // [parity][wave 0..NW][side][slot][72][2 halves] 16-bit entries in dynamic LDS
+    unsigned short* h;
+    __device__ __forceinline__ unsigned short* at(int par, int wave, int side, int slot) const
+    {
+        return h + ((((par * (NW + 1) + wave) * 2 + side) * GH + slot) * (kBuffers * PXL)) * 2;
+    }
 };
 
-__global__ void __launch_bounds__(kMaxWaves * 64, 2) k_fused_u8_v3(Args a)
+__host__ __device__ constexpr int lds_bytes(int nw)
 {
-    __shared__ Mailbox mb;
-    __shared__ Parked parked;
+    return (6 + kLdsBuffers * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
+    Parked<NW * 64> parked;
+    parked.v = reinterpret_cast<uint4*>(lds_raw);
+    parked.a = parked.v + 6 * NW * 64;
+    Mailbox<NW> mb;
+    mb.h = reinterpret_cast<unsigned short*>(parked.a + kLdsBuffers * 2 * NW * 64);
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int nvw = a.nvw;
@@ -514,7 +535,7 @@ __global__ void __launch_bounds__(kMaxWaves * 64, 2) k_fused_u8_v3(Args a)
         if (r > 1 && (r - 1) % K == 0 && !(a.dbg & 1)) {
             __syncthreads();
             if (recv_left || recv_right) {
-                const unsigned* from = reinterpret_cast<const unsigned*>(&mb.h[par][wave][recv_left ? 0 : 1][slot][0][0]);
+                const unsigned* from = reinterpret_cast<const unsigned*>(mb.at(par, wave, recv_left ? 0 : 1, slot));
                 auto merge = [&](int b, unsigned (&Ab)[PXL]) {
 #pragma unroll
                     for (int j = 0; j < PXL; ++j) Ab[j] = bfi(ghost_mask, from[b * PXL + j], Ab[j]);
@@ -537,13 +558,14 @@ __global__ void __launch_bounds__(kMaxWaves * 64, 2) k_fused_u8_v3(Args a)
                 const int wpar = ((r + 1) / K) & 1;
                 if (pub_right || pub_left) {
                     // my lo half feeds the ghost's hi half and vice versa (see Mailbox)
-                    unsigned short(*to_hi)[2] = pub_right ? mb.h[wpar][wave][0][slot] : mb.h[wpar][wave > 0 ? wave - 1 : kMaxWaves][1][slot];
-                    unsigned short(*to_lo)[2] = pub_right ? mb.h[wpar][wave + 1][0][slot] : mb.h[wpar][wave][1][slot];
+                    // (wave - 1 of wave 0 and wave + 1 of the last wave land in the spare slot `nw`)
+                    unsigned short* to_hi = pub_right ? mb.at(wpar, wave, 0, slot) : mb.at(wpar, wave > 0 ? wave - 1 : NW, 1, slot);
+                    unsigned short* to_lo = pub_right ? mb.at(wpar, wave + 1, 0, slot) : mb.at(wpar, wave, 1, slot);
                     auto send = [&](int b, const unsigned (&Ab)[PXL]) {
 #pragma unroll
                         for (int j = 0; j < PXL; ++j) {
-                            to_hi[b * PXL + j][1] = (unsigned short)(Ab[j] & 0xffffu);
-                            to_lo[b * PXL + j][0] = (unsigned short)(Ab[j] >> 16);
+                            to_hi[(b * PXL + j) * 2 + 1] = (unsigned short)(Ab[j] & 0xffffu);
+                            to_lo[(b * PXL + j) * 2 + 0] = (unsigned short)(Ab[j] >> 16);
                         }
                     };
 #pragma unroll
@@ -610,7 +632,20 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
     static const int dbg = [] { const char* e = getenv("SN_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
-    hipLaunchKernelGGL(v3::k_fused_u8_v3, dim3(nframes), dim3(a.nw * 64), 0, st, a);
+    const int lds = v3::lds_bytes(a.nw);
+    hipError_t e = hipSuccess;
+#define SN_LAUNCH(NW)                                                                                        \
+    case NW:                                                                                                 \
+        if (lds > 64 * 1024)                                                                                 \
+            e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL(v3::k_fused_u8_v3<NW>, dim3(nframes), dim3(NW * 64), lds, st, a); \
+        break;
+    switch (a.nw) {
+        SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef SN_LAUNCH
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

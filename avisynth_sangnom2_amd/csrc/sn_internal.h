@@ -45,6 +45,7 @@ hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& 
 // sn_fused_u8.hip: the fused one-pass kernel (8-bit).  launch_fused_u8 also does
 // the plane's frame assembly, so launch_assemble must not be called for a plane it serves.
 bool fused_eligible(const sn_config& c);
+bool fused_v2_plane_ok(int w);
 bool fused_layout_ok(const PlaneArgs& p);
 hipError_t launch_fused_u8(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
 // sn_fused_u8_v3.hip: the same sweep with two virtual wavefronts packed into every register.

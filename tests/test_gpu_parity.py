@@ -179,6 +179,9 @@ FUSED_CASES = [
     ("Y8", 3840, 28, {}),
     ("Y8", 3840, 44, dict(order=2)),     # widest the fused kernel takes (8 waves); > 8 seam refreshes
     ("Y8", 2048, 64, dict(order=2, aa=90)),
+    ("Y8", 4096, 24, {}),                # 5 waves (9 virtual wavefronts, last half-wave dead)
+    ("Y8", 5120, 22, dict(order=2)),
+    ("Y8", 7680, 26, {}),                # 8 waves, 119 KB of LDS
     ("Y8", 256, 2, {}),                  # nothing to interpolate
     ("Y8", 256, 4, dict(order=2)),       # a single interpolated row
     ("Y8", 256, 6, {}),
@@ -205,7 +208,7 @@ def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
 
 def test_fused_not_eligible_is_reported(hip_lib):
     for fmt, w, h, kw in (("Y16", 64, 32, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(aac=1)),
-                          ("Y8", 3872, 16, {})):
+                          ("Y8", 7712, 16, {})):
         with pytest.raises(SangNomError, match="not eligible"):
             SangNom2(clip_format(fmt, w, h), mode="fused", **kw)
 
