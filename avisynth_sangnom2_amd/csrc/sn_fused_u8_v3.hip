@@ -370,8 +370,10 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], const P
 // LDS mailbox, receiver-ready: word [refresh parity][wave W][side][slot][i] is what ghost lane
 // `slot` on that side of wave W loads into packed A register i -- its low half written by one
 // publisher, its high half by another (16-bit LDS stores), so receiving costs no shuffling:
-//   left ghosts  (lanes 0, 1)   of wave W: lo <- wave W-1 lanes 60, 61 hi half; hi <- wave W lanes 60, 61 lo half
-//   right ghosts (lanes 62, 63) of wave W: lo <- wave W lanes 2, 3 hi half;     hi <- wave W+1 lanes 2, 3 lo half
+//   left ghosts  (lanes 0, 1)   of wave W: both halves <- wave W-1 lanes 60, 61 (same half), except that the hi
+//                                          half of wave 0 (strip NW) <- wave NW-1 lanes 60, 61 lo half (strip NW-1)
+//   right ghosts (lanes 62, 63) of wave W: both halves <- wave W+1 lanes 2, 3 (same half), except that the lo
+//                                          half of wave NW-1 (strip NW-1) <- wave 0 lanes 2, 3 hi half (strip NW)
 template <int NW>
 struct Mailbox {  // [parity][wave 0..NW][side][slot][72][2 halves] 16-bit entries in dynamic LDS
     unsigned short* h;
@@ -401,7 +403,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     const int lane = threadIdx.x & 63;
     const int nvw = a.nvw;
 
-    // per-half lane roles: virtual wavefront vw = 2 * wave + half
+    // per-half lane roles: virtual wavefront vw = wave + half * NW (strips in column order; the two
+    // strips of a wave are NW strips apart, so both halves' neighbours sit in the adjacent wave)
     int x0[2];
     bool live[2], real[2], ghost[2];
     LaneRole role;
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     role.last_mask = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int vw = 2 * wave + h;
+        const int vw = wave + h * NW;
         int gl;
         bool g;
         if (vw == 0) {
@@ -509,8 +512,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     // ghost lanes (0, 1 and 62, 63) take one half from each of two published registers.
     const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH;
     const bool pub_left = lane >= GH && lane < 2 * GH;
-    const bool recv_left = lane < GH;        // left ghosts of vw 2W (from wave W-1, hi) and 2W+1 (from wave W, lo)
-    const bool recv_right = lane >= 64 - GH; // right ghosts of vw 2W (from wave W, hi) and 2W+1 (from wave W+1, lo)
+    const bool recv_left = lane < GH;         // left ghosts of both strips
+    const bool recv_right = lane >= 64 - GH;  // right ghosts of both strips
     const unsigned ghost_mask = (ghost[0] && live[0] ? kLo : 0u) | (ghost[1] && live[1] ? kHi : 0u);
     const int slot = recv_left ? lane : recv_right ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
 
@@ -557,15 +560,21 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
             if (r % K == 0 && !(a.dbg & 1)) {
                 const int wpar = ((r + 1) / K) & 1;
                 if (pub_right || pub_left) {
-                    // my lo half feeds the ghost's hi half and vice versa (see Mailbox)
-                    // (wave - 1 of wave 0 and wave + 1 of the last wave land in the spare slot `nw`)
-                    unsigned short* to_hi = pub_right ? mb.at(wpar, wave, 0, slot) : mb.at(wpar, wave > 0 ? wave - 1 : NW, 1, slot);
-                    unsigned short* to_lo = pub_right ? mb.at(wpar, wave + 1, 0, slot) : mb.at(wpar, wave, 1, slot);
+                    // where my two halves go (see Mailbox): entry + position (0 = low half, 1 = high half);
+                    // halves without a neighbour land in the spare entry `NW`
+                    unsigned short *to_lo, *to_hi;  // destinations of my low / high half
+                    if (pub_right) {
+                        to_lo = wave < NW - 1 ? mb.at(wpar, wave + 1, 0, slot) : mb.at(wpar, 0, 0, slot) + 1;
+                        to_hi = wave < NW - 1 ? mb.at(wpar, wave + 1, 0, slot) + 1 : mb.at(wpar, NW, 0, slot);
+                    } else {
+                        to_lo = wave > 0 ? mb.at(wpar, wave - 1, 1, slot) : mb.at(wpar, NW, 1, slot);
+                        to_hi = wave > 0 ? mb.at(wpar, wave - 1, 1, slot) + 1 : mb.at(wpar, NW - 1, 1, slot);
+                    }
                     auto send = [&](int b, const unsigned (&Ab)[PXL]) {
 #pragma unroll
                         for (int j = 0; j < PXL; ++j) {
-                            to_hi[(b * PXL + j) * 2 + 1] = (unsigned short)(Ab[j] & 0xffffu);
-                            to_lo[(b * PXL + j) * 2 + 0] = (unsigned short)(Ab[j] >> 16);
+                            to_lo[(b * PXL + j) * 2] = (unsigned short)(Ab[j] & 0xffffu);
+                            to_hi[(b * PXL + j) * 2] = (unsigned short)(Ab[j] >> 16);
                         }
                     };
 #pragma unroll
