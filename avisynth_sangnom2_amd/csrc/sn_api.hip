@@ -33,6 +33,12 @@ struct Context {
     PoolArgs pool{};
     int slots = 1;
 
+    // fused 8-bit path with subsampled chroma: two scratch pools per batch slot (sn_fused_u8_v3.hip, Mode)
+    bool fused420 = false;
+    uint8_t* fpool[2] = {nullptr, nullptr};
+    int64_t fpool_frame_bytes = 0;
+    int fpool_rows = 0;
+
     // staging for sn_process_host
     uint8_t* stage_src[3] = {nullptr, nullptr, nullptr};
     uint8_t* stage_dst[3] = {nullptr, nullptr, nullptr};
@@ -157,6 +163,8 @@ void sn_destroy(sn_context* h)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->pool.base) (void)hipFree(c->pool.base);
+    for (int i = 0; i < 2; ++i)
+        if (c->fpool[i]) (void)hipFree(c->fpool[i]);
     for (int p = 0; p < 3; ++p) {
         if (c->stage_src[p]) (void)hipFree(c->stage_src[p]);
         if (c->stage_dst[p]) (void)hipFree(c->stage_dst[p]);
@@ -200,6 +208,7 @@ static int create_impl(const sn_config* cfg, Context* c)
         return sn::fail(c, SN_ERR_UNSUPPORTED, "SN_MODE_FUSED requested but this configuration is not eligible");
     c->use_fused = eligible && cfg->mode != SN_MODE_POOL;
 
+    c->fused420 = c->use_fused && sn::fused_needs_pools(c->cfg);
     if (cfg->stream) {
         c->stream = reinterpret_cast<hipStream_t>(cfg->stream);
     } else {
@@ -214,6 +223,15 @@ static int create_impl(const sn_config* cfg, Context* c)
     c->pool.slot_bytes = (c->pool.slot_bytes + 255) & ~(int64_t)255;
     SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->pool.base), (size_t)c->pool.slot_bytes * c->slots));
     SN_HIP(c, hipMemsetAsync(c->pool.base, 0, (size_t)c->pool.slot_bytes * c->slots, c->stream));
+    if (c->fused420) {
+        // rows the chroma sweeps can reach: 1 .. min(nr_c + 2, bh - 1), plus row 0
+        const int nr_c = c->plane_h_out(1) / 2 - 1;
+        const int reach = nr_c + 2 < c->bh - 1 ? nr_c + 2 : c->bh - 1;
+        c->fpool_rows = reach + 1;
+        c->fpool_frame_bytes = sn::fused_v3_pool_bytes(cfg->width, c->fpool_rows);
+        for (int i = 0; i < 2; ++i)
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->slots));
+    }
     SN_HIP(c, hipStreamSynchronize(c->stream));
     return SN_OK;
 }
@@ -284,10 +302,33 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
         if (a.enabled && c->use_fused && sn::fused_layout_ok(a)) {
             // SN_FUSED_VER=2 selects the previous formulation (sn_fused_u8.hip) for A/B runs
             static const int ver = [] { const char* e = getenv("SN_FUSED_VER"); return e ? atoi(e) : 3; }();
-            if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w))
-                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n));
-            else
+            if (c->fused420) {
+                // luma sweep leaves its smoothed rows in pool 0; U reads pool 0 and leaves pool 1; V reads pool 1
+                const int nr_c = c->plane_h_out(1) / 2 - 1;
+                const int reach = c->fpool_rows - 1;
+                sn::FusedPool fp{};
+                fp.sweep_w = c->cfg.width;
+                fp.frame_stride = c->fpool_frame_bytes;
+                fp.pool_rows = c->fpool_rows;
+                if (p == 0) {
+                    fp.mode = 1;
+                    fp.pool_out = c->fpool[0];
+                    fp.rows_out = reach;
+                } else {
+                    fp.mode = 2;
+                    fp.pool_in = c->fpool[p - 1];
+                    fp.pool_out = p == 1 ? c->fpool[1] : nullptr;
+                    const int sweep_u = nr_c + 1 < c->bh - 1 ? nr_c + 1 : c->bh - 1;
+                    fp.rows_in = p == 1 ? reach : sweep_u;
+                    fp.sweep_rows = p == 1 ? sweep_u : nr_c;
+                    fp.rows_out = p == 1 ? sweep_u : 0;
+                }
+                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, &fp));
+            } else if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w)) {
+                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, nullptr));
+            } else {
                 SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));
+            }
             if (p == 0 || !(c->cfg.dh || c->process[0])) c->fused_frames += n;
             continue;
         }

@@ -519,16 +519,26 @@ bool fused_v2_plane_ok(int w)
     return waves_for(w / 4, 4) <= 16 || waves_for(w / 8, 8) <= 8;
 }
 
-// Eligible when every processed plane is 8-bit, as large as the pool (so that no pass can see
-// another pass's leftovers: SURVEY.md 0.7) and narrow enough for one workgroup.
+// Eligible when the clip is 8-bit, narrow enough for one workgroup, and either every processed plane is
+// as large as the pool (no pass can see another pass's leftovers: SURVEY.md 0.7) or the chroma planes are
+// subsampled AND luma is processed first (then the fused kernel couples the passes through scratch pools;
+// without a luma pass the chroma passes would see the previous FRAME's leftovers: pool path).
+static bool chroma_subsampled_and_processed(const sn_config& c)
+{
+    const int np = c.num_planes < 3 ? c.num_planes : 3;
+    return np == 3 && (c.dh || c.chroma) && (c.sub_w != 0 || c.sub_h != 0);
+}
+
+bool fused_needs_pools(const sn_config& c) { return chroma_subsampled_and_processed(c); }
+
 bool fused_eligible(const sn_config& c)
 {
     if (c.bytes_per_sample != 1) return false;
     if (!fused_v3_plane_ok(c.width) && !fused_v2_plane_ok(c.width)) return false;
-    const int np = c.num_planes < 3 ? c.num_planes : 3;
-    for (int p = 1; p < np; ++p) {
-        const bool processed = c.dh || c.chroma;
-        if (processed && (c.sub_w != 0 || c.sub_h != 0)) return false;
+    if (chroma_subsampled_and_processed(c)) {
+        if (!(c.dh || c.luma)) return false;
+        if (!fused_v3_plane_ok(c.width)) return false;
+        if ((c.width >> c.sub_w) % 8 != 0) return false;
     }
     return true;
 }

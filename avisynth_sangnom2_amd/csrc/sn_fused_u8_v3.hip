@@ -57,7 +57,29 @@ struct Args {
     int32_t src_bytes;  // bytes of one source plane (buffer descriptor range)
     int32_t dst_bytes;  // bytes of one destination plane
     int32_t dbg;        // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh (wrong results)
+    // pool coupling for subsampled chroma (modes kLumaSpill / kChroma, see below)
+    const uint8_t* pool_in;   // smoothed buffers left by the previous pass (kChroma)
+    uint8_t* pool_out;        // where this pass leaves its smoothed buffers (kLumaSpill, first kChroma pass)
+    int64_t pool_frame_stride;
+    int32_t pool_rows;        // rows a pool buffer holds (row index 1 .. pool_rows - 1 used)
+    int32_t rows_in;          // rows 1 .. rows_in of pool_in are valid, later rows read as zero
+    int32_t rows_out;         // rows 1 .. rows_out are written to pool_out (0 = none)
+    int32_t region_w;         // kChroma: columns < region_w belong to the chroma plane
+    int32_t sweep_rows;       // kChroma: pool rows to sweep (>= nk - 1)
 };
+
+// The reference's nine buffers are sized for the luma plane and shared by all planes, so a
+// subsampled chroma pass smooths a pool that still holds the previous pass's results outside the
+// chroma region.  Exact emulation in the fused kernel:
+//   kLumaSpill  the luma sweep also leaves its smoothed values O of the rows the chroma passes can
+//               reach in a scratch pool;
+//   kChroma     the sweep runs over the whole luma-wide pool: inside the chroma region the cost of
+//               the next row comes from the chroma lines (stage 1), elsewhere it is the previous
+//               pass's O read back from the pool; stage 3 and the output exist only inside the region.
+// Pool layout: [buffer][row][thread][4 dwords], dword k = O[2k] | O[2k+1] << 8 (packed pairs), i.e. every
+// thread re-reads what the thread with the same columns wrote; ghost lanes read their owner's slot.
+enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2 };
+
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -115,7 +137,9 @@ __device__ __forceinline__ RawHalf load_half(__amdgpu_buffer_rsrc_t rs, int voff
 struct LaneRole {
     bool edge_wave;      // wave holds column 0 or column w-1: clamps needed
     unsigned first_mask; // 0xffff in the half that owns column 0 (else 0)
-    unsigned last_mask;  // 0xffff (shifted) in the half that owns column w-1
+    unsigned last_mask;  // 0xffff (shifted) in the half that owns column w-1 of the sweep
+    unsigned line_last_mask;  // ... that owns the last column of the source lines (kChroma: region_w - 1)
+    unsigned inside_mask;     // kChroma: halves whose columns lie inside the chroma region
 };
 
 // byte k of the lo word -> bits 0..7, byte k of the hi word -> bits 16..23
@@ -135,7 +159,7 @@ __device__ __forceinline__ void unpack(Line& L, Raw q, const LaneRole& role)
                 q.h[h].m0 = q.h[h].l;
                 q.h[h].l = (q.h[h].m0 & 0xff) * 0x01010101u;
             }
-            if (role.last_mask & (h ? kHi : kLo)) q.h[h].r = (q.h[h].m1 >> 24) * 0x01010101u;
+            if (role.line_last_mask & (h ? kHi : kLo)) q.h[h].r = (q.h[h].m1 >> 24) * 0x01010101u;
         }
     }
 #pragma unroll
@@ -227,22 +251,79 @@ __device__ __forceinline__ void box7(const unsigned (&S)[PXL], unsigned (&Bx)[PX
     for (int j = 0; j + 1 < PXL; ++j) Bx[j + 1] = Bx[j] - X(j - 3) + X(j + 4);
 }
 
-template <int BUF, bool HAS_NEXT>
-__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
-                                            const LaneRole& role)
-{
-    unsigned D[PXL], S[PXL], Bx[PXL];
-#pragma unroll
-    for (int j = 0; j < PXL; ++j) {
-        D[j] = HAS_NEXT ? cost<BUF>(n, nn, j) : 0u;
-        S[j] = A[j] + D[j];
+// Access to the scratch pools of the chroma coupling (see Mode).
+struct PoolIO {
+    __amdgpu_buffer_rsrc_t rin, rout;
+    int v_a, v_b;        // voffset of the slot this lane reads (own or owner's), of the second source
+    unsigned keep_mask;  // halves taken from slot a; the others come from slot b with halves swapped
+    bool need_b;         // wave-uniform: some lane of this wave needs slot b
+    int v_out;           // voffset of the slot this lane writes
+    int row_stride, buf_stride;
+
+    // packed pairs of buffer `b`, pool row `row` (row_ok == false: the row does not exist -> zero)
+    __device__ __forceinline__ void load(int b, int row, bool row_ok, unsigned (&P)[PXL]) const
+    {
+        const int soff = b * buf_stride + row * row_stride;
+        const int va = row_ok ? v_a : kOutOfRange;
+        u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rin, va, soff, 0);
+        if (need_b) {
+            const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_b : kOutOfRange, soff, 0);
+            d.x = bfi(keep_mask, d.x, __builtin_amdgcn_alignbit(e.x, e.x, 16));
+            d.y = bfi(keep_mask, d.y, __builtin_amdgcn_alignbit(e.y, e.y, 16));
+            d.z = bfi(keep_mask, d.z, __builtin_amdgcn_alignbit(e.z, e.z, 16));
+            d.w = bfi(keep_mask, d.w, __builtin_amdgcn_alignbit(e.w, e.w, 16));
+        }
+        P[0] = d.x & kByte; P[1] = (d.x >> 8) & kByte;
+        P[2] = d.y & kByte; P[3] = (d.y >> 8) & kByte;
+        P[4] = d.z & kByte; P[5] = (d.z >> 8) & kByte;
+        P[6] = d.w & kByte; P[7] = (d.w >> 8) & kByte;
     }
+    __device__ __forceinline__ void store(int b, int row, const unsigned (&O)[PXL]) const
+    {
+        u32x4 d;
+        d.x = O[0] | (O[1] << 8);
+        d.y = O[2] | (O[3] << 8);
+        d.z = O[4] | (O[5] << 8);
+        d.w = O[6] | (O[7] << 8);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rout, v_out, b * buf_stride + row * row_stride, 0);
+    }
+};
+
+struct RowCtx {  // what a row needs besides the lines
+    int r;          // pool row being smoothed
+    bool next_ok;   // kChroma: row r + 1 exists in pool_in
+    bool spill;     // this row's O goes to pool_out
+};
+
+// S1: the costs of row r+1 come from the lines (n, nn); otherwise they are zero (kPlain /
+// kLumaSpill: row bh is never written) or the previous pass's values (kChroma).
+template <int BUF, int MODE, bool S1>
+__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
+                                            const LaneRole& role, const PoolIO& io, const RowCtx& rc)
+{
+    unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
+    if constexpr (MODE == kChroma) {
+        io.load(BUF, rc.r + 1, rc.next_ok, D);
+        if constexpr (S1) {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) D[j] = bfi(role.inside_mask, cost<BUF>(n, nn, j), D[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) D[j] = S1 ? cost<BUF>(n, nn, j) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) S[j] = A[j] + D[j];
     if (role.edge_wave) box7<true>(S, Bx, role);
     else box7<false>(S, Bx, role);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        A[j] = ((Bx[j] >> 4) & kByte) + D[j];                        // O + D[r+1]
+        O[j] = (Bx[j] >> 4) & kByte;
+        A[j] = O[j] + D[j];                                                  // O + D[r+1]
         kmin[j] = pk_min(kmin[j], (Bx[j] & 0x0ff00ff0u) | rank_of<BUF>());  // (O << 4) | rank
+    }
+    if constexpr (MODE != kPlain) {
+        if (rc.spill) io.store(BUF, rc.r, O);
     }
 }
 
@@ -300,22 +381,24 @@ __device__ __forceinline__ void unpark_line(const Parked<NT>& pk, int tid, Line&
     L.FB[6] = f.x; L.FB[7] = f.y;
 }
 
-template <bool HAS_NEXT, int NT>
+// S3: the row has an interpolated line (stage 3); kChroma sweeps one extra row without one.
+template <int MODE, bool S1, bool S3, int NT>
 __device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], const Parked<NT>& pk, int tid, const Line& n,
-                                        const Line& nn, const LaneRole& role, unsigned thr_key)
+                                        const Line& nn, const LaneRole& role, unsigned thr_key, const PoolIO& io,
+                                        const RowCtx& rc)
 {
     unsigned kmin[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
     auto in_regs = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
-        buffer_step<B, HAS_NEXT>(A[B], kmin, n, nn, role);
+        buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc);
     };
     auto in_lds = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
         unsigned t[PXL];
         load_A(pk, tid, B, t);
-        buffer_step<B, HAS_NEXT>(t, kmin, n, nn, role);
+        buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc);
         store_A(pk, tid, B, t);
     };
     auto run = [&](auto buf) {
@@ -332,6 +415,8 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], const P
     run(std::integral_constant<int, 7>{});
     run(std::integral_constant<int, 8>{});
 
+    Out o{};
+    if constexpr (!S3) return o;
     // winner's rank -> tap sum -> average
     Line c;
     unpark_line(pk, tid, c);
@@ -356,7 +441,6 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], const P
         v[j] = ((r + 0x00010001u) >> 1) & kByte;  // (a + b + 1) >> 1
     }
     // v[j] = lo-strip byte | hi-strip byte << 16  ->  four bytes per dword and strip
-    Out o;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const unsigned t01 = __builtin_amdgcn_perm(v[4 * g + 1], v[4 * g + 0], 0x06020400u);  // [v0.b0, v1.b0, v0.b2, v1.b2]
@@ -388,7 +472,7 @@ __host__ __device__ constexpr int lds_bytes(int nw)
     return (6 + kLdsBuffers * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
 }
 
-template <int NW>
+template <int NW, int MODE>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -410,6 +494,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     LaneRole role;
     role.first_mask = 0;
     role.last_mask = 0;
+    role.line_last_mask = 0;
+    role.inside_mask = 0;
+    const int line_w = MODE == kChroma ? a.region_w : a.w;  // width of the source / destination plane
+    bool line_live[2], line_real[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int vw = wave + h * NW;
@@ -426,10 +514,15 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
         ghost[h] = g;
         real[h] = live[h] && !g;
         x0[h] = gl * PXL;
+        line_live[h] = live[h] && x0[h] < line_w;
+        line_real[h] = real[h] && x0[h] < line_w;
         if (live[h] && gl == 0) role.first_mask |= h ? kHi : kLo;
         if (live[h] && gl == a.nl - 1) role.last_mask |= h ? kHi : kLo;
+        if (line_live[h] && x0[h] + PXL == line_w) role.line_last_mask |= h ? kHi : kLo;
+        if (line_live[h]) role.inside_mask |= h ? kHi : kLo;
     }
-    role.edge_wave = __builtin_amdgcn_readfirstlane(__any((int)(role.first_mask | role.last_mask)) ? 1 : 0) != 0;
+    role.edge_wave =
+        __builtin_amdgcn_readfirstlane(__any((int)(role.first_mask | role.last_mask | role.line_last_mask)) ? 1 : 0) != 0;
 
     // Buffer descriptors of this frame's source / destination plane; rows are addressed through the
     // scalar offset, columns through per-lane voffsets that never change.
@@ -440,8 +533,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     int vload[2], vstore[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        vload[h] = live[h] ? (x0[h] > 0 ? x0[h] - 4 : 0) : kOutOfRange;
-        vstore[h] = real[h] ? x0[h] : kOutOfRange;
+        vload[h] = line_live[h] ? (x0[h] > 0 ? x0[h] - 4 : 0) : kOutOfRange;
+        vstore[h] = line_real[h] ? x0[h] : kOutOfRange;
     }
     const int src_step = (a.dh ? 1 : 2) * a.src_pitch;        // kept line k -> k + 1
     const int src_line = (a.dh ? 0 : a.offset) * a.src_pitch;  // kept line 0
@@ -473,8 +566,39 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
         __builtin_amdgcn_raw_buffer_store_b64(hi, rd, vstore[1], row_off, 0);
     };
 
+    // scratch pools of the chroma coupling
+    PoolIO io{};
+    if constexpr (MODE != kPlain) {
+        const int pool_bytes = kBuffers * a.pool_rows * NW * 64 * 16;
+        io.row_stride = NW * 64 * 16;
+        io.buf_stride = a.pool_rows * io.row_stride;
+        if (MODE == kChroma)
+            io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in + (int64_t)f * a.pool_frame_stride), 0,
+                                                       pool_bytes, 0x00020000);
+        io.rout = __builtin_amdgcn_make_buffer_rsrc(a.pool_out ? a.pool_out + (int64_t)f * a.pool_frame_stride : nullptr, 0,
+                                                    a.pool_out ? pool_bytes : 0, 0x00020000);
+        // the slot a lane reads: its own, or -- for ghost lanes -- the slot of the thread that owns
+        // those columns (lanes 60, 61 of the previous wave / lanes 2, 3 of the next one).  The two
+        // strips of a wave meet their neighbours in the same thread, except at the seam between
+        // strip NW-1 and strip NW, where the partner sits in the other half of another wave.
+        int ta = tid, tb = tid;
+        io.keep_mask = 0xffffffffu;
+        if (lane < GH) {
+            if (wave > 0) ta = (wave - 1) * 64 + (64 - 2 * GH) + lane;
+            else { tb = (NW - 1) * 64 + (64 - 2 * GH) + lane; io.keep_mask = kLo; }  // hi half <- strip NW-1 (a lo half)
+        } else if (lane >= 64 - GH) {
+            if (wave < NW - 1) ta = (wave + 1) * 64 + GH + (lane - (64 - GH));
+            else { tb = GH + (lane - (64 - GH)); io.keep_mask = kHi; }               // lo half <- strip NW (a hi half)
+        }
+        io.v_a = ta * 16;
+        io.v_b = tb * 16;
+        io.need_b = __builtin_amdgcn_readfirstlane(wave == 0 || wave == NW - 1) != 0;
+        io.v_out = (real[0] || real[1]) ? tid * 16 : kOutOfRange;
+    }
+
     const int nk = a.nk;
     const int nr = nk - 1;
+    const int sweep = MODE == kChroma ? a.sweep_rows : nr;
     const unsigned thr_key = (unsigned)((a.thr + 1) << 4) * 0x00010001u;
 
     Line L0, L1;
@@ -487,19 +611,41 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     unpack(L1, q1, role);
     park_line(parked, tid, L0);  // c of row 1
 
-    // A[1] = O[0] + D[1] = D[1] (pool row 0 is never written: zero)
+    // A[1] = O[0] + P[1] = P[1] (pool row 0 is never written: zero); P[1] = stage-1 costs of the first
+    // line pair, and outside the chroma region (kChroma) what the previous pass left in row 1
     unsigned A[kRegBuffers][PXL];
-#define SN_INIT(BUF) _Pragma("unroll") for (int j = 0; j < PXL; ++j) A[BUF][j] = nr > 0 ? cost<BUF>(L0, L1, j) : 0u;
-    SN_INIT(0) SN_INIT(1) SN_INIT(2) SN_INIT(3) SN_INIT(4) SN_INIT(5)
-#undef SN_INIT
-#define SN_INIT_LDS(BUF)                                                                 \
-    {                                                                                    \
-        unsigned t[PXL];                                                                 \
-        _Pragma("unroll") for (int j = 0; j < PXL; ++j) t[j] = nr > 0 ? cost<BUF>(L0, L1, j) : 0u; \
-        store_A(parked, tid, BUF, t);                                                    \
-    }
-    SN_INIT_LDS(6) SN_INIT_LDS(7) SN_INIT_LDS(8)
-#undef SN_INIT_LDS
+    auto init_A = [&](auto buf, unsigned (&Ab)[PXL]) {
+        constexpr int B = decltype(buf)::value;
+        if constexpr (MODE == kChroma) {
+            io.load(B, 1, a.rows_in >= 1, Ab);
+            if (nr > 0) {
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) Ab[j] = bfi(role.inside_mask, cost<B>(L0, L1, j), Ab[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? cost<B>(L0, L1, j) : 0u;
+        }
+    };
+    auto init_buf = [&](auto buf) {
+        constexpr int B = decltype(buf)::value;
+        if constexpr (B < kRegBuffers) {
+            init_A(buf, A[B]);
+        } else {
+            unsigned t[PXL];
+            init_A(buf, t);
+            store_A(parked, tid, B, t);
+        }
+    };
+    init_buf(std::integral_constant<int, 0>{});
+    init_buf(std::integral_constant<int, 1>{});
+    init_buf(std::integral_constant<int, 2>{});
+    init_buf(std::integral_constant<int, 3>{});
+    init_buf(std::integral_constant<int, 4>{});
+    init_buf(std::integral_constant<int, 5>{});
+    init_buf(std::integral_constant<int, 6>{});
+    init_buf(std::integral_constant<int, 7>{});
+    init_buf(std::integral_constant<int, 8>{});
 
     int src_next = src_line + 2 * src_step;
     int dst_keep = dst_line + 2 * dst_step;
@@ -518,15 +664,18 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     const int slot = recv_left ? lane : recv_right ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
 
     Out pending{};
-    auto step = [&](int r, Line& n, Line& nn, auto has_next_tag) {
-        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+    // One pool row r: n = K[r], nn = K[r+1] (S1: the pair exists), c = K[r-1] parked (S3: the row has an
+    // interpolated line).
+    auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
+        constexpr bool HAS_NEXT = decltype(s1_tag)::value;
+        constexpr bool S3 = decltype(s3_tag)::value;
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
             unpack(nn, qn, role);  // waits for the line prefetched one row ago
             keep(dst_keep, qn);
             dst_keep += dst_step;
         }
-        if (r > 1) {
+        if (r > 1 && r <= nr) {
             put(out_row, pending);
             out_row += dst_step;
         }
@@ -554,9 +703,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
                 }
             }
         }
-        pending = row_step<HAS_NEXT>(A, parked, tid, n, nn, role, thr_key);
+        RowCtx rc;
+        rc.r = r;
+        rc.next_ok = r + 1 <= a.rows_in;
+        rc.spill = MODE != kPlain && r <= a.rows_out;
+        pending = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
-        if constexpr (HAS_NEXT) {
+        if (r < sweep) {
             if (r % K == 0 && !(a.dbg & 1)) {
                 const int wpar = ((r + 1) / K) & 1;
                 if (pub_right || pub_left) {
@@ -593,14 +746,19 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     using T = std::integral_constant<bool, true>;
     using F = std::integral_constant<bool, false>;
 
-    // L1 = K[r] (n), L0 is reused for K[r+1] (nn); c lives in LDS
+    // L1 = K[r] (n), L0 is reused for K[r+1] (nn); c lives in LDS.  Rows 1 .. nr-1 have a following line
+    // pair, row nr does not (its next costs are zero or stale), rows beyond nr (kChroma only) have no
+    // interpolated line either.
     for (int r = 1; r < nr; ++r) {
-        step(r, L1, L0, T{});
+        step(r, L1, L0, T{}, T{});
         L1 = L0;
     }
     if (nr >= 1) {
-        step(nr, L1, L0, F{});
+        step(nr, L1, L0, F{}, T{});
         put(out_row, pending);
+    }
+    if constexpr (MODE == kChroma) {
+        for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
     }
 
     // dst row h-1 := K[nk-1] when the top field is kept, SangNom2.cpp:380-385
@@ -620,34 +778,21 @@ bool fused_v3_plane_ok(int w)
     return v3::virtual_waves_for(w / v3::PXL) <= 2 * v3::kMaxWaves;
 }
 
-hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes)
+int fused_v3_waves(int sweep_w) { return (v3::virtual_waves_for(sweep_w / v3::PXL) + 1) / 2; }
+
+// bytes of one scratch pool of one frame: [9][rows][threads][16]
+int64_t fused_v3_pool_bytes(int sweep_w, int rows) { return (int64_t)kBuffers * rows * fused_v3_waves(sweep_w) * 64 * 16; }
+
+template <int MODE>
+static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
 {
-    v3::Args a{};
-    a.src = p.src;
-    a.dst = p.dst;
-    a.src_frame_stride = p.src_frame_stride;
-    a.dst_frame_stride = p.dst_frame_stride;
-    a.src_pitch = p.src_pitch;
-    a.dst_pitch = p.dst_pitch;
-    a.w = p.w;
-    a.nk = p.h_out / 2;
-    a.offset = p.offset;
-    a.dh = p.dh;
-    a.thr = (int)threshold;
-    a.nl = p.w / v3::PXL;
-    a.nvw = v3::virtual_waves_for(a.nl);
-    a.nw = (a.nvw + 1) / 2;
-    a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
-    a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
-    static const int dbg = [] { const char* e = getenv("SN_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
     const int lds = v3::lds_bytes(a.nw);
     hipError_t e = hipSuccess;
-#define SN_LAUNCH(NW)                                                                                        \
-    case NW:                                                                                                 \
-        if (lds > 64 * 1024)                                                                                 \
-            e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL(v3::k_fused_u8_v3<NW>, dim3(nframes), dim3(NW * 64), lds, st, a); \
+#define SN_LAUNCH(NW)                                                                                              \
+    case NW:                                                                                                       \
+        if (lds > 64 * 1024)                                                                                       \
+            e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((v3::k_fused_u8_v3<NW, MODE>), dim3(nframes), dim3(NW * 64), lds, st, a); \
         break;
     switch (a.nw) {
         SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
@@ -656,6 +801,42 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
 #undef SN_LAUNCH
     if (e != hipSuccess) return e;
     return hipGetLastError();
+}
+
+// pool == nullptr: a plane on its own (kPlain).  Otherwise pool->mode selects kLumaSpill / kChroma and
+// pool->sweep_w is the luma width the sweep covers (p describes the plane being interpolated).
+hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool)
+{
+    v3::Args a{};
+    a.src = p.src;
+    a.dst = p.dst;
+    a.src_frame_stride = p.src_frame_stride;
+    a.dst_frame_stride = p.dst_frame_stride;
+    a.src_pitch = p.src_pitch;
+    a.dst_pitch = p.dst_pitch;
+    a.w = pool ? pool->sweep_w : p.w;
+    a.nk = p.h_out / 2;
+    a.offset = p.offset;
+    a.dh = p.dh;
+    a.thr = (int)threshold;
+    a.nl = a.w / v3::PXL;
+    a.nvw = v3::virtual_waves_for(a.nl);
+    a.nw = (a.nvw + 1) / 2;
+    a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
+    a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
+    static const int dbg = [] { const char* e = getenv("SN_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    if (!pool) return launch_mode<v3::kPlain>(st, a, nframes);
+    a.pool_in = pool->pool_in;
+    a.pool_out = pool->pool_out;
+    a.pool_frame_stride = pool->frame_stride;
+    a.pool_rows = pool->pool_rows;
+    a.rows_in = pool->rows_in;
+    a.rows_out = pool->pool_out ? pool->rows_out : 0;
+    a.region_w = p.w;
+    a.sweep_rows = pool->sweep_rows;
+    if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
+    return launch_mode<v3::kChroma>(st, a, nframes);
 }
 
 }  // namespace sn

@@ -45,11 +45,25 @@ hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& 
 // sn_fused_u8.hip: the fused one-pass kernel (8-bit).  launch_fused_u8 also does
 // the plane's frame assembly, so launch_assemble must not be called for a plane it serves.
 bool fused_eligible(const sn_config& c);
+bool fused_needs_pools(const sn_config& c);  // subsampled chroma: luma / chroma sweeps coupled through scratch pools
 bool fused_v2_plane_ok(int w);
 bool fused_layout_ok(const PlaneArgs& p);
 hipError_t launch_fused_u8(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
 // sn_fused_u8_v3.hip: the same sweep with two virtual wavefronts packed into every register.
 bool fused_v3_plane_ok(int w);
-hipError_t launch_fused_u8_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
+// Scratch-pool coupling between the luma sweep and the subsampled-chroma sweeps (sn_fused_u8_v3.hip, Mode).
+struct FusedPool {
+    int mode;                // 1 = luma sweep that leaves its smoothed rows, 2 = chroma sweep
+    int sweep_w;             // luma width (the pool's width)
+    const uint8_t* pool_in;  // chroma: what the previous pass left
+    uint8_t* pool_out;       // luma / first chroma pass: where this pass leaves its rows (may be null)
+    int64_t frame_stride;    // bytes between the pools of consecutive frames
+    int pool_rows;           // rows per pool buffer
+    int rows_in, rows_out;   // valid rows in pool_in / rows to write to pool_out
+    int sweep_rows;          // chroma: pool rows to sweep
+};
+int fused_v3_waves(int sweep_w);
+int64_t fused_v3_pool_bytes(int sweep_w, int rows);
+hipError_t launch_fused_u8_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool);
 
 }  // namespace sn

@@ -188,6 +188,17 @@ FUSED_CASES = [
     ("Y8", 640, 40, dict(dh=True)),
     ("YUV444P8", 576, 24, dict(aac=48)),
     ("YUV420P8", 576, 24, dict(chroma=False)),  # luma fused, chroma copied
+    # subsampled chroma: luma and chroma sweeps coupled through the scratch pools (shared-pool emulation)
+    ("YUV420P8", 64, 32, dict(aac=48)),
+    ("YUV420P8", 128, 64, dict(aac=30, order=2)),
+    ("YUV420P8", 1024, 40, dict(aac=48)),          # chroma region ends inside a strip
+    ("YUV420P8", 1984, 24, dict(aac=48, order=0)),
+    ("YUV420P8", 3840, 48, dict(aac=48)),
+    ("YUV420P8", 96, 8, dict(aac=48)),             # a single interpolated chroma row
+    ("YUV420P8", 96, 4, dict(aac=48)),             # chroma planes too short to interpolate
+    ("YUV422P8", 576, 28, dict(aac=48)),           # chroma as tall as luma
+    ("YUV420P8", 320, 20, dict(dh=True, aac=48)),
+    ("YUV420P8", 320, 36, dict(aac=0)),            # aac = 0: only exact-zero minima leave the vertical average
 ]
 
 
@@ -207,7 +218,7 @@ def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
 
 
 def test_fused_not_eligible_is_reported(hip_lib):
-    for fmt, w, h, kw in (("Y16", 64, 32, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(aac=1)),
+    for fmt, w, h, kw in (("Y16", 64, 32, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(luma=False, aac=1)),
                           ("Y8", 7712, 16, {})):
         with pytest.raises(SangNomError, match="not eligible"):
             SangNom2(clip_format(fmt, w, h), mode="fused", **kw)
