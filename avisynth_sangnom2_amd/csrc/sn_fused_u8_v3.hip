@@ -260,50 +260,66 @@ struct PoolIO {
     int v_out;           // voffset of the slot this lane writes
     int row_stride, buf_stride;
 
-    // packed pairs of buffer `b`, pool row `row` (row_ok == false: the row does not exist -> zero)
-    __device__ __forceinline__ void load(int b, int row, bool row_ok, unsigned (&P)[PXL]) const
+    struct RawPair {
+        u32x4 a, b;
+    };
+    // issue the load(s) of buffer `b`, pool row `row` (row_ok == false: the row does not exist -> zero)
+    __device__ __forceinline__ RawPair issue(int b, int row, bool row_ok) const
     {
         const int soff = b * buf_stride + row * row_stride;
-        const int va = row_ok ? v_a : kOutOfRange;
-        u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rin, va, soff, 0);
+        RawPair q;
+        q.a = __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_a : kOutOfRange, soff, 0);
+        q.b = q.a;
+        if (need_b) q.b = __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_b : kOutOfRange, soff, 0);
+        return q;
+    }
+    // ... and turn them into packed pairs
+    __device__ __forceinline__ void finish(const RawPair& q, unsigned (&P)[PXL]) const
+    {
+        u32x4 d = q.a;
         if (need_b) {
-            const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_b : kOutOfRange, soff, 0);
-            d.x = bfi(keep_mask, d.x, __builtin_amdgcn_alignbit(e.x, e.x, 16));
-            d.y = bfi(keep_mask, d.y, __builtin_amdgcn_alignbit(e.y, e.y, 16));
-            d.z = bfi(keep_mask, d.z, __builtin_amdgcn_alignbit(e.z, e.z, 16));
-            d.w = bfi(keep_mask, d.w, __builtin_amdgcn_alignbit(e.w, e.w, 16));
+            d.x = bfi(keep_mask, d.x, __builtin_amdgcn_alignbit(q.b.x, q.b.x, 16));
+            d.y = bfi(keep_mask, d.y, __builtin_amdgcn_alignbit(q.b.y, q.b.y, 16));
+            d.z = bfi(keep_mask, d.z, __builtin_amdgcn_alignbit(q.b.z, q.b.z, 16));
+            d.w = bfi(keep_mask, d.w, __builtin_amdgcn_alignbit(q.b.w, q.b.w, 16));
         }
         P[0] = d.x & kByte; P[1] = (d.x >> 8) & kByte;
         P[2] = d.y & kByte; P[3] = (d.y >> 8) & kByte;
         P[4] = d.z & kByte; P[5] = (d.z >> 8) & kByte;
         P[6] = d.w & kByte; P[7] = (d.w >> 8) & kByte;
     }
-    __device__ __forceinline__ void store(int b, int row, const unsigned (&O)[PXL]) const
+    __device__ __forceinline__ void load(int b, int row, bool row_ok, unsigned (&P)[PXL]) const
+    {
+        finish(issue(b, row, row_ok), P);
+    }
+    // vout: v_out, or kOutOfRange for rows that are not kept (the store is then dropped: no branch)
+    __device__ __forceinline__ void store(int b, int row, int vout, const unsigned (&O)[PXL]) const
     {
         u32x4 d;
         d.x = O[0] | (O[1] << 8);
         d.y = O[2] | (O[3] << 8);
         d.z = O[4] | (O[5] << 8);
         d.w = O[6] | (O[7] << 8);
-        __builtin_amdgcn_raw_buffer_store_b128(d, rout, v_out, b * buf_stride + row * row_stride, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rout, vout, b * buf_stride + row * row_stride, 0);
     }
 };
 
 struct RowCtx {  // what a row needs besides the lines
     int r;          // pool row being smoothed
     bool next_ok;   // kChroma: row r + 1 exists in pool_in
-    bool spill;     // this row's O goes to pool_out
+    int vout;       // voffset for this row's O in pool_out (out of range: not kept)
 };
 
 // S1: the costs of row r+1 come from the lines (n, nn); otherwise they are zero (kPlain /
 // kLumaSpill: row bh is never written) or the previous pass's values (kChroma).
 template <int BUF, int MODE, bool S1>
 __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
-                                            const LaneRole& role, const PoolIO& io, const RowCtx& rc)
+                                            const LaneRole& role, const PoolIO& io, const RowCtx& rc,
+                                            const PoolIO::RawPair& stale)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
     if constexpr (MODE == kChroma) {
-        io.load(BUF, rc.r + 1, rc.next_ok, D);
+        io.finish(stale, D);
         if constexpr (S1) {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) D[j] = bfi(role.inside_mask, cost<BUF>(n, nn, j), D[j]);
@@ -322,9 +338,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
         A[j] = O[j] + D[j];                                                  // O + D[r+1]
         kmin[j] = pk_min(kmin[j], (Bx[j] & 0x0ff00ff0u) | rank_of<BUF>());  // (O << 4) | rank
     }
-    if constexpr (MODE != kPlain) {
-        if (rc.spill) io.store(BUF, rc.r, O);
-    }
+    if constexpr (MODE != kPlain) io.store(BUF, rc.r, rc.vout, O);
 }
 
 struct Out {
@@ -335,31 +349,34 @@ struct Out {
 // nine buffer steps.  It is parked in LDS while they run (each lane reads back exactly the 24 dwords
 // it wrote itself, so no barrier is involved) -- that keeps the kernel inside 256 VGPRs without
 // scratch spills, whose reloads would park a wave that has only one partner on its SIMD.
-constexpr int kRegBuffers = 6;                      // buffers 0..5 keep their A state in VGPRs,
-constexpr int kLdsBuffers = kBuffers - kRegBuffers;  // buffers 6..8 keep it in LDS between their steps
-template <int NT>
+// Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
+// The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
+// in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == 0 ? 6 : 4; }
+template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
+    static constexpr int kRegBuffers = RB;
     uint4* v;    // [6][NT]: the parked line
-    uint4* a;    // [kLdsBuffers][2][NT]: A of the LDS-resident buffers, thread-private slots
+    uint4* a;    // [kBuffers - RB][2][NT]: A of the LDS-resident buffers, thread-private slots
 };
 
-template <int NT>
-__device__ __forceinline__ void load_A(const Parked<NT>& pk, int tid, int b, unsigned (&A)[PXL])
+template <int NT, int RB>
+__device__ __forceinline__ void load_A(const Parked<NT, RB>& pk, int tid, int b, unsigned (&A)[PXL])
 {
-    const uint4 x = pk.a[((b - kRegBuffers) * 2 + 0) * pk.nthreads + tid], y = pk.a[((b - kRegBuffers) * 2 + 1) * pk.nthreads + tid];
+    const uint4 x = pk.a[((b - RB) * 2 + 0) * pk.nthreads + tid], y = pk.a[((b - RB) * 2 + 1) * pk.nthreads + tid];
     A[0] = x.x; A[1] = x.y; A[2] = x.z; A[3] = x.w;
     A[4] = y.x; A[5] = y.y; A[6] = y.z; A[7] = y.w;
 }
-template <int NT>
-__device__ __forceinline__ void store_A(const Parked<NT>& pk, int tid, int b, const unsigned (&A)[PXL])
+template <int NT, int RB>
+__device__ __forceinline__ void store_A(const Parked<NT, RB>& pk, int tid, int b, const unsigned (&A)[PXL])
 {
-    pk.a[((b - kRegBuffers) * 2 + 0) * pk.nthreads + tid] = make_uint4(A[0], A[1], A[2], A[3]);
-    pk.a[((b - kRegBuffers) * 2 + 1) * pk.nthreads + tid] = make_uint4(A[4], A[5], A[6], A[7]);
+    pk.a[((b - RB) * 2 + 0) * pk.nthreads + tid] = make_uint4(A[0], A[1], A[2], A[3]);
+    pk.a[((b - RB) * 2 + 1) * pk.nthreads + tid] = make_uint4(A[4], A[5], A[6], A[7]);
 }
 
-template <int NT>
-__device__ __forceinline__ void park_line(const Parked<NT>& pk, int tid, const Line& L)
+template <int NT, int RB>
+__device__ __forceinline__ void park_line(const Parked<NT, RB>& pk, int tid, const Line& L)
 {
     pk.v[0 * pk.nthreads + tid] = make_uint4(L.P[0], L.P[1], L.P[2], L.P[3]);
     pk.v[1 * pk.nthreads + tid] = make_uint4(L.P[4], L.P[5], L.P[6], L.P[7]);
@@ -369,8 +386,8 @@ __device__ __forceinline__ void park_line(const Parked<NT>& pk, int tid, const L
     pk.v[5 * pk.nthreads + tid] = make_uint4(L.FB[6], L.FB[7], 0u, 0u);
 }
 
-template <int NT>
-__device__ __forceinline__ void unpark_line(const Parked<NT>& pk, int tid, Line& L)
+template <int NT, int RB>
+__device__ __forceinline__ void unpark_line(const Parked<NT, RB>& pk, int tid, Line& L)
 {
     const uint4 a = pk.v[0 * pk.nthreads + tid], b = pk.v[1 * pk.nthreads + tid], c = pk.v[2 * pk.nthreads + tid], d = pk.v[3 * pk.nthreads + tid], e = pk.v[4 * pk.nthreads + tid], f = pk.v[5 * pk.nthreads + tid];
     L.P[0] = a.x; L.P[1] = a.y; L.P[2] = a.z; L.P[3] = a.w;
@@ -383,27 +400,31 @@ __device__ __forceinline__ void unpark_line(const Parked<NT>& pk, int tid, Line&
 
 // S3: the row has an interpolated line (stage 3); kChroma sweeps one extra row without one.
 template <int MODE, bool S1, bool S3, int NT>
-__device__ __forceinline__ Out row_step(unsigned (&A)[kRegBuffers][PXL], const Parked<NT>& pk, int tid, const Line& n,
+__device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk, int tid, const Line& n,
                                         const Line& nn, const LaneRole& role, unsigned thr_key, const PoolIO& io,
                                         const RowCtx& rc)
 {
     unsigned kmin[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
-    auto in_regs = [&](auto buf) {
-        constexpr int B = decltype(buf)::value;
-        buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc);
-    };
-    auto in_lds = [&](auto buf) {
-        constexpr int B = decltype(buf)::value;
-        unsigned t[PXL];
-        load_A(pk, tid, B, t);
-        buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc);
-        store_A(pk, tid, B, t);
-    };
+    // kChroma: the previous pass's row r+1 is fetched one buffer ahead of its use (HBM latency), and the
+    // scheduler is kept from hoisting all nine fetches (their registers would spill).
+    PoolIO::RawPair st0{}, st1{};
+    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.next_ok);
     auto run = [&](auto buf) {
-        if constexpr (decltype(buf)::value < kRegBuffers) in_regs(buf);
-        else in_lds(buf);
+        constexpr int B = decltype(buf)::value;
+        if constexpr (MODE == kChroma) {
+            if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.next_ok);
+        }
+        if constexpr (B < reg_buffers(MODE)) {
+            buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st0);
+        } else {
+            unsigned t[PXL];
+            load_A(pk, tid, B, t);
+            buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st0);
+            store_A(pk, tid, B, t);
+        }
+        if constexpr (MODE == kChroma) st0 = st1;
     };
     run(std::integral_constant<int, 0>{});
     run(std::integral_constant<int, 1>{});
@@ -467,9 +488,9 @@ struct Mailbox {  // [parity][wave 0..NW][side][slot][72][2 halves] 16-bit entri
     }
 };
 
-__host__ __device__ constexpr int lds_bytes(int nw)
+__host__ __device__ constexpr int lds_bytes(int nw, int mode)
 {
-    return (6 + kLdsBuffers * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
+    return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
 }
 
 template <int NW, int MODE>
@@ -478,11 +499,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
-    Parked<NW * 64> parked;
+    constexpr int kRegBuffers = reg_buffers(MODE);
+    Parked<NW * 64, kRegBuffers> parked;
     parked.v = reinterpret_cast<uint4*>(lds_raw);
     parked.a = parked.v + 6 * NW * 64;
     Mailbox<NW> mb;
-    mb.h = reinterpret_cast<unsigned short*>(parked.a + kLdsBuffers * 2 * NW * 64);
+    mb.h = reinterpret_cast<unsigned short*>(parked.a + (kBuffers - kRegBuffers) * 2 * NW * 64);
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int nvw = a.nvw;
@@ -706,7 +728,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
         RowCtx rc;
         rc.r = r;
         rc.next_ok = r + 1 <= a.rows_in;
-        rc.spill = MODE != kPlain && r <= a.rows_out;
+        rc.vout = (MODE != kPlain && r <= a.rows_out) ? io.v_out : kOutOfRange;
         pending = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
         if (r < sweep) {
@@ -786,7 +808,7 @@ int64_t fused_v3_pool_bytes(int sweep_w, int rows) { return (int64_t)kBuffers * 
 template <int MODE>
 static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
 {
-    const int lds = v3::lds_bytes(a.nw);
+    const int lds = v3::lds_bytes(a.nw, MODE);
     hipError_t e = hipSuccess;
 #define SN_LAUNCH(NW)                                                                                              \
     case NW:                                                                                                       \
