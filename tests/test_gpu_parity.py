@@ -246,3 +246,56 @@ def test_fused_equals_pool_at_full_size(hip_lib):
     assert np.array_equal(outs["fused"], outs["pool"])
     want = Oracle(oracle_cfg(clip)).process([src[0][2].cpu().numpy()])
     assert same(want[0], outs["fused"][2])
+
+
+# ---- BASELINE.json's configurations at full size ----------------------------------------------------
+# The oracle needs ~0.1-0.5 s per full-size frame, so each configuration checks ONE frame against it and
+# a small batch through a size-independent property: the fused kernel and the pool path (two independent
+# GPU implementations; the pool path mirrors the reference's three stages and its shared pool literally)
+# must agree bit for bit on every frame of the batch.
+
+FULL_SIZE = [
+    ("1080p Y8", "Y8", 1920, 1080, dict(order=1, aa=48), 3),
+    ("2160p YUV420P8", "YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48), 2),
+    ("4320p Y8", "Y8", 7680, 4320, dict(order=1, aa=48), 2),
+]
+
+
+@pytest.mark.parametrize("name,fmt,w,h,kw,N", FULL_SIZE, ids=[c[0] for c in FULL_SIZE])
+def test_full_size_fused_equals_pool_and_oracle(hip_lib, name, fmt, w, h, kw, N):
+    import torch
+    clip = clip_format(fmt, w, h)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(2026)
+    shapes = [(h >> (clip.subh if p else 0), w >> (clip.subw if p else 0)) for p in range(clip.planes)]
+    src = [torch.randint(0, 256, (N,) + sh, device=dev, generator=g, dtype=torch.uint8) for sh in shapes]
+    for p, sh in enumerate(shapes):  # one hard 0/255 checker frame: maximises the wrap paths of stage 2
+        src[p][N - 1] = torch.from_numpy(synth.plane(sh[0], sh[1], 1, 8, "checker", p)).to(dev)
+    outs = {}
+    for mode in ("fused", "pool"):
+        with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
+            dst = [torch.zeros((N,) + sh, device=dev, dtype=torch.uint8) for sh in shapes]
+            torch.cuda.synchronize()
+            flt.process_batch(src, dst)
+            flt.synchronize()
+            outs[mode] = [d.cpu().numpy() for d in dst]
+    for p in range(clip.planes):
+        assert np.array_equal(outs["fused"][p], outs["pool"][p]), f"{name}: plane {p} differs between fused and pool"
+    want = Oracle(oracle_cfg(clip, **kw)).process([s[0].cpu().numpy() for s in src])
+    for p in range(clip.planes):
+        assert same(want[p], outs["fused"][p][0]), f"{name}: plane {p} differs from the oracle"
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", [("YUV420P16", 3840, 2160, dict(aa=48, aac=48)),
+                                        ("YUV444PS", 3840, 1080, dict(aa=48, aac=48, dh=True))],
+                         ids=["2160p YUV420P16", "2160p-out YUV444PS dh"])
+def test_full_size_16bit_and_float_match_oracle(hip_lib, fmt, w, h, kw):
+    """BASELINE configuration 4 at full size, one frame each, against the oracle (float: bit patterns)."""
+    clip = clip_format(fmt, w, h)
+    src = synth.frame(clip, "noise", seed=77)
+    want = Oracle(oracle_cfg(clip, **kw)).process(src)
+    with SangNom2(clip, **kw) as flt:
+        got = flt.get_frame(src)
+    for p in range(3):
+        assert same(want[p], got[p]), f"{fmt} plane {p}: " + describe_diff(want[p], got[p])
