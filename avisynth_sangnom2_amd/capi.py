@@ -21,7 +21,7 @@ MODES = {"auto": SN_MODE_AUTO, "pool": SN_MODE_POOL, "fused": SN_MODE_FUSED}
 EXPORTS = (
     "sn_abi_version", "sn_validate", "sn_create", "sn_destroy", "sn_last_error",
     "sn_process_host", "sn_process_device", "sn_process_device_strided", "sn_synchronize",
-    "sn_get_stream", "sn_get_info", "sn_debug_read_pool",
+    "sn_get_stream", "sn_get_info", "sn_debug_read_pool", "sn_debug_read_coupled_rows",
 )
 
 
@@ -37,7 +37,8 @@ class SnInfo(ctypes.Structure):
                 ("pool_stride", ctypes.c_int32), ("pool_rows", ctypes.c_int32),
                 ("fused_eligible", ctypes.c_int32), ("history_free", ctypes.c_int32),
                 ("frames", ctypes.c_int64), ("fused_frames", ctypes.c_int64),
-                ("fused_tiles_rejected", ctypes.c_int64), ("threshold", ctypes.c_double * 3)]
+                ("coupled_rows", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("threshold", ctypes.c_double * 3)]
 
 
 def build(force: bool = False) -> str:
@@ -95,5 +96,6 @@ def load():
     L.sn_get_stream.restype = vp
     L.sn_get_info.argtypes = [vp, ctypes.POINTER(SnInfo)]
     L.sn_debug_read_pool.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    L.sn_debug_read_coupled_rows.argtypes = [vp, i32, vp, ctypes.c_size_t]
     _lib = L
     return L

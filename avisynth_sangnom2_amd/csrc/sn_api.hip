@@ -11,6 +11,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 #include "sn_internal.h"
 
@@ -228,9 +229,13 @@ static int create_impl(const sn_config* cfg, Context* c)
         const int nr_c = c->plane_h_out(1) / 2 - 1;
         const int reach = nr_c + 2 < c->bh - 1 ? nr_c + 2 : c->bh - 1;
         c->fpool_rows = reach + 1;
-        c->fpool_frame_bytes = sn::fused_v3_pool_bytes(cfg->width, c->fpool_rows);
+        c->fpool_frame_bytes = cfg->bytes_per_sample == 2 ? sn::fused_u16_pool_bytes(cfg->width, c->fpool_rows)
+                                                          : sn::fused_v3_pool_bytes(cfg->width, c->fpool_rows);
         for (int i = 0; i < 2; ++i)
+        {
             SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->slots));
+            if (const char* e = getenv("SN_DEBUG_FILL")) SN_HIP(c, hipMemset(c->fpool[i], atoi(e), (size_t)c->fpool_frame_bytes * c->slots));
+        }
     }
     SN_HIP(c, hipStreamSynchronize(c->stream));
     return SN_OK;
@@ -323,7 +328,10 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
                     fp.sweep_rows = p == 1 ? sweep_u : nr_c;
                     fp.rows_out = p == 1 ? sweep_u : 0;
                 }
-                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, &fp));
+                if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, &fp));
+                else SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, &fp));
+            } else if (c->cfg.bytes_per_sample == 2) {
+                SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, nullptr));
             } else if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w)) {
                 SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, nullptr));
             } else {
@@ -438,7 +446,8 @@ int sn_get_info(sn_context* h, sn_info* info)
     info->history_free = c->history_free ? 1 : 0;
     info->frames = c->frames;
     info->fused_frames = c->fused_frames;
-    info->fused_tiles_rejected = 0;
+    info->coupled_rows = c->fused420 ? c->fpool_rows : 0;
+    info->reserved0 = 0;
     for (int p = 0; p < 3; ++p) info->threshold[p] = p < c->nplanes() ? c->threshold(p) : 0.0;
     return SN_OK;
 }
@@ -453,6 +462,22 @@ int sn_debug_read_pool(sn_context* h, int32_t slot, void* host_dst, size_t bytes
     SN_HIP(c, hipSetDevice(c->device));
     SN_HIP(c, hipStreamSynchronize(c->stream));
     SN_HIP(c, hipMemcpy(host_dst, c->pool.base + (int64_t)slot * c->pool.slot_bytes, need, hipMemcpyDeviceToHost));
+    return SN_OK;
+}
+
+int sn_debug_read_coupled_rows(sn_context* h, int32_t which, void* host_dst, size_t bytes)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    const size_t need = (size_t)sn::kBuffers * c->fpool_rows * c->cfg.width * c->cfg.bytes_per_sample;
+    if (!c->fused420 || which < 0 || which > 1 || !c->fpool[which] || !host_dst || bytes < need)
+        return sn::fail(c, SN_ERR_INVALID_ARG, "sn_debug_read_coupled_rows: no such hand-off or buffer too small (%zu needed)", need);
+    SN_HIP(c, hipSetDevice(c->device));
+    SN_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> raw((size_t)c->fpool_frame_bytes / 4);
+    SN_HIP(c, hipMemcpy(raw.data(), c->fpool[which], (size_t)c->fpool_frame_bytes, hipMemcpyDeviceToHost));
+    if (c->cfg.bytes_per_sample == 2) sn::fused_u16_pool_unpack(raw.data(), c->cfg.width, c->fpool_rows, static_cast<uint16_t*>(host_dst));
+    else sn::fused_v3_pool_unpack(raw.data(), c->cfg.width, c->fpool_rows, static_cast<uint8_t*>(host_dst));
     return SN_OK;
 }
 

@@ -1,0 +1,644 @@
+// sn_fused_u16_v3.hip -- the fused sweep for 9..16-bit samples (uint16 containers).
+//
+// Same algorithm, exactness argument and structure as sn_fused_u8_v3.hip (read its header): one
+// workgroup sweeps one plane top to bottom, a lane owns 8 consecutive pixels of a row, the nine cost
+// buffers live in registers / thread-private LDS as A[r] = O[r-1] + D[r], ghost lanes keep wave seams
+// exact with one barrier every 5 rows, subsampled chroma is coupled to the luma sweep through scratch
+// pools (Mode).  16-bit sums need up to 21 bits, so a register holds ONE pixel
+// here: one strip per wave, up to 8 waves = 3840 pixels.
+//
+// Reference semantics: /root/reference/src/SangNom2.cpp:60-65 (wrap to uint16_t, arithmetic >> 3),
+// :74-124, :126-159 (sum / 16 wraps to uint16_t), :161-257, :361-391.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "sn_fused_v3_common.h"
+
+namespace sn {
+namespace w16 {
+
+using namespace v3c;
+constexpr int kMaxWaves = 8;
+constexpr unsigned kVal = 0xffffu;
+
+__device__ __forceinline__ unsigned absdiff(unsigned a, unsigned b)  // both < 65536
+{
+    return __builtin_amdgcn_sad_u16(a, b, 0u);
+}
+__device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+
+struct Line {
+    unsigned P[PXL + 6];  // P[i] = pixel x0 - 3 + i (edge-clamped)
+    unsigned FB[PXL];     // F | B << 16: the two SangNom values (calculateSangNom, SangNom2.cpp:60-65)
+    __device__ __forceinline__ unsigned F(int j) const { return FB[j] & kVal; }
+    __device__ __forceinline__ unsigned B(int j) const { return FB[j] >> 16; }
+};
+
+struct Raw {  // bytes [2(x0-4), 2(x0+12)): pixels x0-4 .. x0+11 as 8 dwords
+    u32x4 a, b;
+};
+
+struct LaneRole {
+    bool edge_wave;  // wave holds the first or last column of the sweep or of the source lines
+    bool first;      // lane owns column 0
+    bool last;       // lane owns the last column of the sweep
+    bool line_last;  // lane owns the last column of the source lines (kChroma: region_w - 1)
+    bool inside;     // kChroma: the lane's columns lie inside the chroma region
+    unsigned first_mask, last_mask;  // all ones where first / last
+};
+
+__device__ __forceinline__ void unpack(Line& L, const Raw& q, const LaneRole& role)
+{
+    // dword i of (a, b) holds pixels x0 - 4 + 2i (low half) and x0 - 3 + 2i; the lane that owns column 0
+    // loaded from column 0 instead, so its dwords are two slots early
+    unsigned d[8] = {q.a.x, q.a.y, q.a.z, q.a.w, q.b.x, q.b.y, q.b.z, q.b.w};
+    if (role.edge_wave && role.first) {
+#pragma unroll
+        for (int i = 7; i >= 2; --i) d[i] = d[i - 2];
+    }
+    L.P[0] = d[0] >> 16;
+#pragma unroll
+    for (int i = 1; i < 7; ++i) {
+        L.P[2 * i - 1] = d[i] & kVal;
+        L.P[2 * i] = d[i] >> 16;
+    }
+    L.P[13] = d[7] & kVal;
+    if (role.edge_wave) {  // loadPixel's clamp, SangNom2.cpp:25-34
+        if (role.first) L.P[0] = L.P[1] = L.P[2] = L.P[3];
+        if (role.line_last) L.P[11] = L.P[12] = L.P[13] = L.P[10];
+    }
+    // F = ((4a + 5b - c) >> 3) mod 65536, B likewise mirrored; a bias of 8 * 65536 keeps the sum positive
+    // and drops out of the result
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        const unsigned a = L.P[j + 2], b = L.P[j + 3], c = L.P[j + 4];
+        const unsigned x5 = 4 * b + b + 0x80000u;
+        const unsigned f = ((4 * a + x5 - c) >> 3) & kVal;
+        const unsigned bb = ((4 * c + x5 - a) >> 3) & kVal;
+        L.FB[j] = f | (bb << 16);
+    }
+}
+
+template <int BUF>
+__device__ __forceinline__ unsigned cost(const Line& c, const Line& n, int j)
+{
+    const int i = j + 3;
+    if constexpr (BUF == 0) return absdiff(c.P[i - 3], n.P[i + 3]);
+    if constexpr (BUF == 1) return absdiff(c.P[i - 2], n.P[i + 2]);
+    if constexpr (BUF == 2) return absdiff(c.P[i - 1], n.P[i + 1]);
+    if constexpr (BUF == 3) return absdiff(c.F(j), n.B(j));
+    if constexpr (BUF == 4) return absdiff(c.P[i], n.P[i]);
+    if constexpr (BUF == 5) return absdiff(c.B(j), n.F(j));
+    if constexpr (BUF == 6) return absdiff(c.P[i + 1], n.P[i - 1]);
+    if constexpr (BUF == 7) return absdiff(c.P[i + 2], n.P[i - 2]);
+    return absdiff(c.P[i + 3], n.P[i - 3]);
+}
+
+template <int BUF>
+__device__ __forceinline__ unsigned tap_sum(const Line& c, const Line& n, int j)
+{
+    const int i = j + 3;
+    if constexpr (BUF == 0) return c.P[i - 3] + n.P[i + 3];
+    if constexpr (BUF == 1) return c.P[i - 2] + n.P[i + 2];
+    if constexpr (BUF == 2) return c.P[i - 1] + n.P[i + 1];
+    if constexpr (BUF == 3) return c.F(j) + n.B(j);
+    if constexpr (BUF == 4) return c.P[i] + n.P[i];
+    if constexpr (BUF == 5) return c.B(j) + n.F(j);
+    if constexpr (BUF == 6) return c.P[i + 1] + n.P[i - 1];
+    if constexpr (BUF == 7) return c.P[i + 2] + n.P[i - 2];
+    return c.P[i + 3] + n.P[i - 3];
+}
+
+template <int BUF>
+constexpr unsigned rank_of()  // P4, P5, P3, P6, P2, P7, P1, P8, P0 -> 1..9 (SangNom2.cpp:214-249)
+{
+    constexpr unsigned r[9] = {9, 7, 5, 3, 1, 2, 4, 6, 8};
+    return r[BUF];
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void box7(const unsigned (&S)[PXL], unsigned (&Bx)[PXL], const LaneRole& role)
+{
+    unsigned L[3], R[3];
+    if constexpr (EDGE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // bitwise selects, not ?: -- a DPP read executed under a lane mask would see the masked-off
+            // source lanes as invalid (zero)
+            L[k] = bfi(role.first_mask, S[0], dpp_from_left(S[PXL - 3 + k]));  // clamp to column 0
+            R[k] = bfi(role.last_mask, S[PXL - 1], dpp_from_right(S[k]));      // clamp to column w-1
+        }
+    }
+    auto X = [&](int i) -> unsigned {
+        if (i < 0) return EDGE ? L[i + 3] : dpp_from_left(S[PXL + i]);
+        if (i >= PXL) return EDGE ? R[i - PXL] : dpp_from_right(S[i - PXL]);
+        return S[i];
+    };
+    Bx[0] = S[0] + S[1] + S[2] + S[3] + X(-1) + X(-2) + X(-3);
+#pragma unroll
+    for (int j = 0; j + 1 < PXL; ++j) Bx[j + 1] = Bx[j] - X(j - 3) + X(j + 4);
+}
+
+// Scratch pools of the chroma coupling: [buffer][row][thread][4 dwords], dword k = O[2k] | O[2k+1] << 16.
+struct PoolIO {
+    __amdgpu_buffer_rsrc_t rin, rout;
+    int v_a;    // slot this lane reads: its own, or its owner's for ghost lanes
+    int v_out;  // slot this lane writes
+    int row_stride, buf_stride;
+
+    __device__ __forceinline__ u32x4 issue(int b, int row, bool row_ok) const
+    {
+        return __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_a : kOutOfRange, b * buf_stride + row * row_stride, 0);
+    }
+    __device__ __forceinline__ void finish(const u32x4& d, unsigned (&P)[PXL]) const
+    {
+        P[0] = d.x & kVal; P[1] = d.x >> 16;
+        P[2] = d.y & kVal; P[3] = d.y >> 16;
+        P[4] = d.z & kVal; P[5] = d.z >> 16;
+        P[6] = d.w & kVal; P[7] = d.w >> 16;
+    }
+    __device__ __forceinline__ void store(int b, int row, int vout, const unsigned (&O)[PXL]) const
+    {
+        u32x4 d;
+        d.x = O[0] | (O[1] << 16);
+        d.y = O[2] | (O[3] << 16);
+        d.z = O[4] | (O[5] << 16);
+        d.w = O[6] | (O[7] << 16);
+        store_b128(d, rout, vout, b * buf_stride + row * row_stride);
+    }
+};
+
+struct RowCtx {
+    int r;
+    bool next_ok;
+    int vout;
+};
+
+template <int BUF, int MODE, bool S1>
+__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
+                                            const LaneRole& role, const PoolIO& io, const RowCtx& rc, const u32x4& stale)
+{
+    unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
+    if constexpr (MODE == kChroma) {
+        io.finish(stale, D);
+        if constexpr (S1) {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) D[j] = role.inside ? cost<BUF>(n, nn, j) : D[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) D[j] = S1 ? cost<BUF>(n, nn, j) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) S[j] = A[j] + D[j];
+    if (role.edge_wave) box7<true>(S, Bx, role);
+    else box7<false>(S, Bx, role);
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        O[j] = (Bx[j] >> 4) & kVal;  // (sum / 16) wraps to uint16_t, SangNom2.cpp:152
+        A[j] = O[j] + D[j];
+        kmin[j] = umin(kmin[j], (Bx[j] & 0xffff0u) | rank_of<BUF>());  // (O << 4) | rank
+    }
+    if constexpr (MODE != kPlain) io.store(BUF, rc.r, rc.vout, O);
+}
+
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == 0 ? 6 : 4; }
+
+template <int NT, int RB>
+struct Parked {
+    uint4* v;  // [6][NT]: the parked line
+    uint4* a;  // [9 - RB][2][NT]: A of the LDS-resident buffers
+    __device__ __forceinline__ void load_A(int tid, int b, unsigned (&A)[PXL]) const
+    {
+        const uint4 x = a[((b - RB) * 2 + 0) * NT + tid], y = a[((b - RB) * 2 + 1) * NT + tid];
+        A[0] = x.x; A[1] = x.y; A[2] = x.z; A[3] = x.w;
+        A[4] = y.x; A[5] = y.y; A[6] = y.z; A[7] = y.w;
+    }
+    __device__ __forceinline__ void store_A(int tid, int b, const unsigned (&A)[PXL]) const
+    {
+        a[((b - RB) * 2 + 0) * NT + tid] = make_uint4(A[0], A[1], A[2], A[3]);
+        a[((b - RB) * 2 + 1) * NT + tid] = make_uint4(A[4], A[5], A[6], A[7]);
+    }
+    __device__ __forceinline__ void park(int tid, const Line& L) const
+    {
+        v[0 * NT + tid] = make_uint4(L.P[0], L.P[1], L.P[2], L.P[3]);
+        v[1 * NT + tid] = make_uint4(L.P[4], L.P[5], L.P[6], L.P[7]);
+        v[2 * NT + tid] = make_uint4(L.P[8], L.P[9], L.P[10], L.P[11]);
+        v[3 * NT + tid] = make_uint4(L.P[12], L.P[13], L.FB[0], L.FB[1]);
+        v[4 * NT + tid] = make_uint4(L.FB[2], L.FB[3], L.FB[4], L.FB[5]);
+        v[5 * NT + tid] = make_uint4(L.FB[6], L.FB[7], 0u, 0u);
+    }
+    __device__ __forceinline__ void unpark(int tid, Line& L) const
+    {
+        const uint4 a0 = v[0 * NT + tid], b = v[1 * NT + tid], c = v[2 * NT + tid], d = v[3 * NT + tid],
+                    e = v[4 * NT + tid], f = v[5 * NT + tid];
+        L.P[0] = a0.x; L.P[1] = a0.y; L.P[2] = a0.z; L.P[3] = a0.w;
+        L.P[4] = b.x; L.P[5] = b.y; L.P[6] = b.z; L.P[7] = b.w;
+        L.P[8] = c.x; L.P[9] = c.y; L.P[10] = c.z; L.P[11] = c.w;
+        L.P[12] = d.x; L.P[13] = d.y; L.FB[0] = d.z; L.FB[1] = d.w;
+        L.FB[2] = e.x; L.FB[3] = e.y; L.FB[4] = e.z; L.FB[5] = e.w;
+        L.FB[6] = f.x; L.FB[7] = f.y;
+    }
+};
+
+struct Out {
+    u32x4 v;  // 8 interpolated 16-bit pixels
+};
+
+template <int MODE, bool S1, bool S3, int NT>
+__device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk,
+                                        int tid, const Line& n, const Line& nn, const LaneRole& role, unsigned thr_key,
+                                        const PoolIO& io, const RowCtx& rc)
+{
+    unsigned kmin[PXL];
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
+    u32x4 st0{}, st1{};
+    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.next_ok);
+    auto run = [&](auto buf) {
+        constexpr int B = decltype(buf)::value;
+        if constexpr (MODE == kChroma) {
+            if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.next_ok);
+        }
+        if constexpr (B < reg_buffers(MODE)) {
+            buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st0);
+        } else {
+            unsigned t[PXL];
+            pk.load_A(tid, B, t);
+            buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st0);
+            pk.store_A(tid, B, t);
+        }
+        if constexpr (MODE == kChroma) st0 = st1;
+    };
+    run(std::integral_constant<int, 0>{});
+    run(std::integral_constant<int, 1>{});
+    run(std::integral_constant<int, 2>{});
+    run(std::integral_constant<int, 3>{});
+    run(std::integral_constant<int, 4>{});
+    run(std::integral_constant<int, 5>{});
+    run(std::integral_constant<int, 6>{});
+    run(std::integral_constant<int, 7>{});
+    run(std::integral_constant<int, 8>{});
+
+    Out o{};
+    if constexpr (!S3) return o;
+    Line c;
+    pk.unpark(tid, c);
+    unsigned v[PXL];
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        const unsigned wk = kmin[j];
+        const unsigned m0 = 0u - (wk & 1u);
+        const unsigned m1 = 0u - ((wk >> 1) & 1u);
+        const unsigned m2 = 0u - ((wk >> 2) & 1u);
+        const unsigned m3 = 0u - ((wk >> 3) & 1u);
+        // ranks: 0,1 -> P4; 2 -> P5; 3 -> P3; 4 -> P6; 5 -> P2; 6 -> P7; 7 -> P1; 8 -> P8; 9 -> P0
+        const unsigned a01 = tap_sum<4>(c, n, j);
+        const unsigned a23 = bfi(m0, tap_sum<3>(c, n, j), tap_sum<5>(c, n, j));
+        const unsigned a45 = bfi(m0, tap_sum<2>(c, n, j), tap_sum<6>(c, n, j));
+        const unsigned a67 = bfi(m0, tap_sum<1>(c, n, j), tap_sum<7>(c, n, j));
+        const unsigned a89 = bfi(m0, tap_sum<0>(c, n, j), tap_sum<8>(c, n, j));
+        const unsigned b0 = bfi(m1, a23, a01);
+        const unsigned b1 = bfi(m1, a67, a45);
+        const unsigned c0 = bfi(m2, b1, b0);
+        const unsigned r = bfi(m3, a89, c0);
+        v[j] = (r + 1u) >> 1;  // (a + b + 1) >> 1, at most 65535
+    }
+    o.v.x = v[0] | (v[1] << 16);
+    o.v.y = v[2] | (v[3] << 16);
+    o.v.z = v[4] | (v[5] << 16);
+    o.v.w = v[6] | (v[7] << 16);
+    return o;
+}
+
+// LDS mailbox: [refresh parity][wave][side][slot][72 A registers]; ghost lane `slot` on `side` of wave W
+// loads what the seam lanes of the neighbouring wave published.
+template <int NW>
+struct Mailbox {
+    unsigned* h;
+    __device__ __forceinline__ unsigned* at(int par, int wave, int side, int slot) const
+    {
+        return h + (((par * (NW + 1) + wave) * 2 + side) * GH + slot) * (kBuffers * PXL);
+    }
+};
+
+__host__ __device__ constexpr int lds_bytes(int nw, int mode)
+{
+    return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
+}
+
+template <int NW, int MODE>
+__global__ void __launch_bounds__(NW * 64, 2) k_fused_u16_v3(Args a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int RB = reg_buffers(MODE);
+    constexpr int NT = NW * 64;
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    Parked<NT, RB> parked;
+    parked.v = reinterpret_cast<uint4*>(lds_raw);
+    parked.a = parked.v + 6 * NT;
+    Mailbox<NW> mb;
+    mb.h = reinterpret_cast<unsigned*>(parked.a + (kBuffers - RB) * 2 * NT);
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+
+    // lane -> column group: wave 0 owns lanes 0..61 (all 64 if it is the only wave), later waves own
+    // lanes 2..61 (the last one up to 63); the other lanes are ghosts of the neighbouring wave
+    int gl;
+    bool ghost;
+    if (wave == 0) {
+        gl = lane;
+        ghost = (NW > 1) && lane >= 64 - GH;
+    } else {
+        gl = kFirst + kInner * (wave - 1) + (lane - GH);
+        ghost = lane < GH || (lane >= 64 - GH && wave < NW - 1);
+    }
+    const bool live = gl < a.nl;
+    const bool real = live && !ghost;
+    const int x0 = gl * PXL;
+    const int line_w = MODE == kChroma ? a.region_w : a.w;
+    const bool line_live = live && x0 < line_w;
+    const bool line_real = real && x0 < line_w;
+    LaneRole role;
+    role.first = live && gl == 0;
+    role.last = live && gl == a.nl - 1;
+    role.line_last = line_live && x0 + PXL == line_w;
+    role.inside = line_live;
+    role.first_mask = role.first ? 0xffffffffu : 0u;
+    role.last_mask = role.last ? 0xffffffffu : 0u;
+    role.edge_wave = __builtin_amdgcn_readfirstlane(__any((int)(role.first || role.last || role.line_last)) ? 1 : 0) != 0;
+
+    // buffer descriptors: row in the scalar offset, column in a constant per-lane voffset; dead lanes carry
+    // an out-of-range voffset (loads return zero, stores are dropped)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.src + (int64_t)f * a.src_frame_stride), 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd =
+        __builtin_amdgcn_make_buffer_rsrc(a.dst + (int64_t)f * a.dst_frame_stride, 0, a.dst_bytes, 0x00020000);
+    const int vload = line_live ? (x0 > 0 ? 2 * (x0 - 4) : 0) : kOutOfRange;
+    const int vstore = line_real ? 2 * x0 : kOutOfRange;
+    const int src_step = (a.dh ? 1 : 2) * a.src_pitch;
+    const int src_line = (a.dh ? 0 : a.offset) * a.src_pitch;
+    const int dst_step = 2 * a.dst_pitch;
+    const int dst_line = a.offset * a.dst_pitch;
+
+    auto load_raw = [&](int row_off) {
+        Raw q;
+        q.a = __builtin_amdgcn_raw_buffer_load_b128(rs, vload, row_off, 0);
+        q.b = __builtin_amdgcn_raw_buffer_load_b128(rs, vload, row_off + 16, 0);
+        return q;
+    };
+    auto keep = [&](int row_off, const Raw& q) {  // GetFrame's field copy: the lane's own 8 pixels
+        u32x4 v;
+        if (role.first) v = q.a;                       // loaded from column 0: own pixels come first
+        else { v.x = q.a.z; v.y = q.a.w; v.z = q.b.x; v.w = q.b.y; }
+        store_b128(v, rd, vstore, row_off);
+    };
+    auto put = [&](int row_off, const Out& o) { store_b128(o.v, rd, vstore, row_off); };
+
+    PoolIO io{};
+    if constexpr (MODE != kPlain) {
+        const int pool_bytes = kBuffers * a.pool_rows * NT * 16;
+        io.row_stride = NT * 16;
+        io.buf_stride = a.pool_rows * io.row_stride;
+        if (MODE == kChroma)
+            io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in + (int64_t)f * a.pool_frame_stride), 0,
+                                                       pool_bytes, 0x00020000);
+        io.rout = __builtin_amdgcn_make_buffer_rsrc(a.pool_out ? a.pool_out + (int64_t)f * a.pool_frame_stride : nullptr, 0,
+                                                    a.pool_out ? pool_bytes : 0, 0x00020000);
+        int ta = tid;  // ghost lanes read the slot of the thread that owns their columns
+        if (lane < GH && wave > 0) ta = (wave - 1) * 64 + (64 - 2 * GH) + lane;
+        if (lane >= 64 - GH && wave < NW - 1) ta = (wave + 1) * 64 + GH + (lane - (64 - GH));
+        io.v_a = ta * 16;
+        io.v_out = real ? tid * 16 : kOutOfRange;
+    }
+
+    const int nk = a.nk;
+    const int nr = nk - 1;
+    const int sweep = MODE == kChroma ? a.sweep_rows : nr;
+    const unsigned thr_key = (unsigned)(a.thr + 1) << 4;
+
+    Line L0, L1;
+    Raw q0 = load_raw(src_line);
+    Raw q1 = nk > 1 ? load_raw(src_line + src_step) : q0;
+    keep(dst_line, q0);
+    if (a.offset == 1) keep(0, q0);  // the line that cannot be interpolated, SangNom2.cpp:386-391
+    if (nk > 1) keep(dst_line + dst_step, q1);
+    unpack(L0, q0, role);
+    unpack(L1, q1, role);
+    parked.park(tid, L0);
+
+    // A[1] = O[0] + P[1] = P[1]
+    unsigned A[RB][PXL];
+    auto init_A = [&](auto buf, unsigned (&Ab)[PXL]) {
+        constexpr int B = decltype(buf)::value;
+        if constexpr (MODE == kChroma) {
+            io.finish(io.issue(B, 1, a.rows_in >= 1), Ab);
+            if (nr > 0) {
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) Ab[j] = role.inside ? cost<B>(L0, L1, j) : Ab[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? cost<B>(L0, L1, j) : 0u;
+        }
+    };
+    auto init_buf = [&](auto buf) {
+        constexpr int B = decltype(buf)::value;
+        if constexpr (B < RB) {
+            init_A(buf, A[B]);
+        } else {
+            unsigned t[PXL];
+            init_A(buf, t);
+            parked.store_A(tid, B, t);
+        }
+    };
+    init_buf(std::integral_constant<int, 0>{});
+    init_buf(std::integral_constant<int, 1>{});
+    init_buf(std::integral_constant<int, 2>{});
+    init_buf(std::integral_constant<int, 3>{});
+    init_buf(std::integral_constant<int, 4>{});
+    init_buf(std::integral_constant<int, 5>{});
+    init_buf(std::integral_constant<int, 6>{});
+    init_buf(std::integral_constant<int, 7>{});
+    init_buf(std::integral_constant<int, 8>{});
+
+    int src_next = src_line + 2 * src_step;
+    int dst_keep = dst_line + 2 * dst_step;
+    int out_row = dst_line + a.dst_pitch;
+    Raw qn = nk > 2 ? load_raw(src_next) : q1;
+    src_next += src_step;
+
+    // seam exchange: lanes 60, 61 feed the next wave's left ghosts, lanes 2, 3 the previous wave's right ghosts
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < NW - 1;
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    Out pending{};
+    auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
+        constexpr bool S1 = decltype(s1_tag)::value;
+        constexpr bool S3 = decltype(s3_tag)::value;
+        Raw qnext = qn;
+        if constexpr (S1) {
+            unpack(nn, qn, role);  // waits for the line prefetched one row ago
+            keep(dst_keep, qn);
+            dst_keep += dst_step;
+        }
+        if (r > 1 && r <= nr) {
+            put(out_row, pending);  // stored here, after the prefetch wait (vmcnt counts in order)
+            out_row += dst_step;
+        }
+        if constexpr (S1) {
+            if (r + 2 <= nr) qnext = load_raw(src_next);
+            src_next += src_step;
+        }
+        const int par = (r / K) & 1;
+        if (r > 1 && (r - 1) % K == 0) {
+            __syncthreads();
+            if (recv) {
+                const unsigned* from = mb.at(par, wave, lane < GH ? 0 : 1, slot);
+#pragma unroll
+                for (int b = 0; b < RB; ++b)
+#pragma unroll
+                    for (int j = 0; j < PXL; ++j) A[b][j] = from[b * PXL + j];
+#pragma unroll
+                for (int b = RB; b < kBuffers; ++b) {
+                    unsigned t[PXL];
+#pragma unroll
+                    for (int j = 0; j < PXL; ++j) t[j] = from[b * PXL + j];
+                    parked.store_A(tid, b, t);
+                }
+            }
+        }
+        RowCtx rc;
+        rc.r = r;
+        rc.next_ok = r + 1 <= a.rows_in;
+        rc.vout = (MODE != kPlain && r <= a.rows_out) ? io.v_out : kOutOfRange;
+        pending = row_step<MODE, S1, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
+        if constexpr (S1) parked.park(tid, n);  // n is the next row's c
+        if (r < sweep && r % K == 0) {
+            const int wpar = ((r + 1) / K) & 1;
+            if (pub_right || pub_left) {
+                unsigned* to = pub_right ? mb.at(wpar, wave + 1, 0, slot) : mb.at(wpar, wave - 1, 1, slot);
+#pragma unroll
+                for (int b = 0; b < RB; ++b)
+#pragma unroll
+                    for (int j = 0; j < PXL; ++j) to[b * PXL + j] = A[b][j];
+#pragma unroll
+                for (int b = RB; b < kBuffers; ++b) {
+                    unsigned t[PXL];
+                    parked.load_A(tid, b, t);
+#pragma unroll
+                    for (int j = 0; j < PXL; ++j) to[b * PXL + j] = t[j];
+                }
+            }
+        }
+        qn = qnext;
+    };
+    using T = std::integral_constant<bool, true>;
+    using F = std::integral_constant<bool, false>;
+
+    for (int r = 1; r < nr; ++r) {
+        step(r, L1, L0, T{}, T{});
+        L1 = L0;
+    }
+    if (nr >= 1) {
+        step(nr, L1, L0, F{}, T{});
+        put(out_row, pending);
+    }
+    if constexpr (MODE == kChroma) {
+        for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+    }
+
+    // dst row h-1 := K[nk-1] when the top field is kept, SangNom2.cpp:380-385
+    if (a.offset == 0) {
+        const Raw q = load_raw(src_line + (nk - 1) * src_step);
+        keep((2 * nk - 1) * a.dst_pitch, q);
+    }
+}
+
+template <int MODE>
+static hipError_t launch_mode(hipStream_t st, const Args& a, int nframes)
+{
+    const int lds = lds_bytes(a.nw, MODE);
+    hipError_t e = hipSuccess;
+#define SN_LAUNCH(NW)                                                                                              \
+    case NW:                                                                                                       \
+        if (lds > 64 * 1024)                                                                                       \
+            e = hipFuncSetAttribute((const void*)k_fused_u16_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_fused_u16_v3<NW, MODE>), dim3(nframes), dim3(NW * 64), lds, st, a); \
+        break;
+    switch (a.nw) {
+        SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef SN_LAUNCH
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace w16
+
+bool fused_u16_plane_ok(int w)
+{
+    if (w % 32 != 0) return false;
+    return v3c::strips_for(w / v3c::PXL) <= w16::kMaxWaves;
+}
+
+int fused_u16_waves(int sweep_w) { return v3c::strips_for(sweep_w / v3c::PXL); }
+
+int64_t fused_u16_pool_bytes(int sweep_w, int rows) { return (int64_t)kBuffers * rows * fused_u16_waves(sweep_w) * 64 * 16; }
+
+// Slot of thread t, dword k = O[2k] | O[2k+1] << 16 of the 8 columns the lane owns (PoolIO::store); ghost
+// lanes and lanes past the sweep width own nothing.
+void fused_u16_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint16_t* out)
+{
+    using namespace v3c;
+    const int nl = sweep_w / PXL, nw = strips_for(nl), nt = nw * 64;
+    for (int64_t br = 0; br < (int64_t)kBuffers * rows; ++br)
+        for (int t = 0; t < nt; ++t) {
+            const int wave = t / 64, lane = t % 64;
+            const int gl = wave == 0 ? lane : kFirst + kInner * (wave - 1) + (lane - GH);
+            const bool ghost = wave == 0 ? (nw > 1 && lane >= 64 - GH) : (lane < GH || (lane >= 64 - GH && wave < nw - 1));
+            if (ghost || gl >= nl) continue;
+            const uint32_t* d = raw + (br * nt + t) * 4;
+            uint16_t* o = out + br * sweep_w + gl * PXL;
+            for (int k = 0; k < 4; ++k) { o[2 * k] = (uint16_t)d[k]; o[2 * k + 1] = (uint16_t)(d[k] >> 16); }
+        }
+}
+
+hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool)
+{
+    v3c::Args a{};
+    a.src = p.src;
+    a.dst = p.dst;
+    a.src_frame_stride = p.src_frame_stride;
+    a.dst_frame_stride = p.dst_frame_stride;
+    a.src_pitch = p.src_pitch;
+    a.dst_pitch = p.dst_pitch;
+    a.w = pool ? pool->sweep_w : p.w;
+    a.nk = p.h_out / 2;
+    a.offset = p.offset;
+    a.dh = p.dh;
+    a.thr = (int)threshold;
+    a.nl = a.w / v3c::PXL;
+    a.nvw = v3c::strips_for(a.nl);
+    a.nw = a.nvw;
+    a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
+    a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
+    if (!pool) return w16::launch_mode<v3c::kPlain>(st, a, nframes);
+    a.pool_in = pool->pool_in;
+    a.pool_out = pool->pool_out;
+    a.pool_frame_stride = pool->frame_stride;
+    a.pool_rows = pool->pool_rows;
+    a.rows_in = pool->rows_in;
+    a.rows_out = pool->pool_out ? pool->rows_out : 0;
+    a.region_w = p.w;
+    a.sweep_rows = pool->sweep_rows;
+    if (pool->mode == v3c::kLumaSpill) return w16::launch_mode<v3c::kLumaSpill>(st, a, nframes);
+    return w16::launch_mode<v3c::kChroma>(st, a, nframes);
+}
+
+}  // namespace sn

@@ -533,11 +533,16 @@ bool fused_needs_pools(const sn_config& c) { return chroma_subsampled_and_proces
 
 bool fused_eligible(const sn_config& c)
 {
-    if (c.bytes_per_sample != 1) return false;
-    if (!fused_v3_plane_ok(c.width) && !fused_v2_plane_ok(c.width)) return false;
+    if (c.bytes_per_sample == 2) {
+        if (!fused_u16_plane_ok(c.width)) return false;
+    } else if (c.bytes_per_sample == 1) {
+        if (!fused_v3_plane_ok(c.width) && !fused_v2_plane_ok(c.width)) return false;
+    } else {
+        return false;
+    }
     if (chroma_subsampled_and_processed(c)) {
         if (!(c.dh || c.luma)) return false;
-        if (!fused_v3_plane_ok(c.width)) return false;
+        if (c.bytes_per_sample == 1 && !fused_v3_plane_ok(c.width)) return false;
         if ((c.width >> c.sub_w) % 8 != 0) return false;
     }
     return true;

@@ -26,83 +26,14 @@
 
 #include <type_traits>
 
-#include "sn_internal.h"
+#include "sn_fused_v3_common.h"
 
 namespace sn {
 namespace v3 {
 
-constexpr int PXL = 8;           // pixels per lane and per virtual wavefront
-constexpr int GH = 2;            // ghost lanes on each inner side of a virtual wavefront
-constexpr int K = GH * PXL / 3;  // rows between two seam refreshes (5)
-constexpr int kFirst = 64 - GH;      // real lanes of virtual wavefront 0
-constexpr int kInner = 64 - 2 * GH;  // real lanes of every later virtual wavefront
+using namespace v3c;
 constexpr int kMaxWaves = 8;         // physical waves per workgroup (16 virtual wavefronts, 7680 pixels)
 constexpr unsigned kLo = 0x0000ffffu, kHi = 0xffff0000u, kByte = 0x00ff00ffu;
-
-struct Args {
-    const uint8_t* src;
-    uint8_t* dst;
-    int64_t src_frame_stride;
-    int64_t dst_frame_stride;
-    int32_t src_pitch;
-    int32_t dst_pitch;
-    int32_t w;
-    int32_t nk;      // kept lines
-    int32_t offset;  // first kept line in dst
-    int32_t dh;
-    int32_t thr;
-    int32_t nl;      // real lanes = w / 8
-    int32_t nvw;     // virtual wavefronts
-    int32_t nw;      // physical waves
-    int32_t src_bytes;  // bytes of one source plane (buffer descriptor range)
-    int32_t dst_bytes;  // bytes of one destination plane
-    int32_t dbg;        // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh (wrong results)
-    // pool coupling for subsampled chroma (modes kLumaSpill / kChroma, see below)
-    const uint8_t* pool_in;   // smoothed buffers left by the previous pass (kChroma)
-    uint8_t* pool_out;        // where this pass leaves its smoothed buffers (kLumaSpill, first kChroma pass)
-    int64_t pool_frame_stride;
-    int32_t pool_rows;        // rows a pool buffer holds (row index 1 .. pool_rows - 1 used)
-    int32_t rows_in;          // rows 1 .. rows_in of pool_in are valid, later rows read as zero
-    int32_t rows_out;         // rows 1 .. rows_out are written to pool_out (0 = none)
-    int32_t region_w;         // kChroma: columns < region_w belong to the chroma plane
-    int32_t sweep_rows;       // kChroma: pool rows to sweep (>= nk - 1)
-};
-
-// The reference's nine buffers are sized for the luma plane and shared by all planes, so a
-// subsampled chroma pass smooths a pool that still holds the previous pass's results outside the
-// chroma region.  Exact emulation in the fused kernel:
-//   kLumaSpill  the luma sweep also leaves its smoothed values O of the rows the chroma passes can
-//               reach in a scratch pool;
-//   kChroma     the sweep runs over the whole luma-wide pool: inside the chroma region the cost of
-//               the next row comes from the chroma lines (stage 1), elsewhere it is the previous
-//               pass's O read back from the pool; stage 3 and the output exist only inside the region.
-// Pool layout: [buffer][row][thread][4 dwords], dword k = O[2k] | O[2k+1] << 8 (packed pairs), i.e. every
-// thread re-reads what the thread with the same columns wrote; ghost lanes read their owner's slot.
-enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2 };
-
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned dpp_from_left(unsigned v)
-{
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-}
-__device__ __forceinline__ unsigned dpp_from_right(unsigned v)
-{
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-}
-__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
-{
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
-{
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-// |a - b| in both halves (values < 32768 per half)
-__device__ __forceinline__ unsigned pk_absdiff(unsigned a, unsigned b) { return pk_max(a, b) - pk_min(a, b); }
-// (m & x) | (~m & y): v_bfi_b32
-__device__ __forceinline__ unsigned bfi(unsigned m, unsigned x, unsigned y) { return (m & x) | (~m & y); }
 
 // One kept line: P[i] = pixel (x0 - 3 + i) of both strips, F / B = the two SangNom values per pixel
 // (calculateSangNom, SangNom2.cpp:60-65), all packed lo | hi << 16.
@@ -120,9 +51,6 @@ struct Raw {
     RawHalf h[2];
 };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int kOutOfRange = 0x7fffffff;  // voffset that the buffer range check always rejects
 
 // One 16-byte buffer load per strip and line: bytes [x0 - 4, x0 + 12) = left dword, own 8 bytes,
 // right dword.  Row base in soffset (wave-uniform), column in voffset; dead lanes carry an
@@ -300,7 +228,7 @@ struct PoolIO {
         d.y = O[2] | (O[3] << 8);
         d.z = O[4] | (O[5] << 8);
         d.w = O[6] | (O[7] << 8);
-        __builtin_amdgcn_raw_buffer_store_b128(d, rout, vout, b * buf_stride + row * row_stride, 0);
+        store_b128(d, rout, vout, b * buf_stride + row * row_stride);
     }
 };
 
@@ -790,7 +718,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     }
 }
 
-static int virtual_waves_for(int nl) { return nl <= 64 ? 1 : 1 + (nl - kFirst + kInner - 1) / kInner; }
+static int virtual_waves_for(int nl) { return strips_for(nl); }
 
 }  // namespace v3
 
@@ -804,6 +732,25 @@ int fused_v3_waves(int sweep_w) { return (v3::virtual_waves_for(sweep_w / v3::PX
 
 // bytes of one scratch pool of one frame: [9][rows][threads][16]
 int64_t fused_v3_pool_bytes(int sweep_w, int rows) { return (int64_t)kBuffers * rows * fused_v3_waves(sweep_w) * 64 * 16; }
+
+// Slot of thread t, dword k: bytes 0, 1 = columns 2k, 2k+1 of the strip in the low halves (strip `wave`),
+// bytes 2, 3 = the same of the strip in the high halves (strip `wave + nw`), as PoolIO::store packs them.
+void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* out)
+{
+    using namespace v3c;
+    const int nl = sweep_w / PXL, nvw = v3::virtual_waves_for(nl), nw = (nvw + 1) / 2, nt = nw * 64;
+    for (int64_t br = 0; br < (int64_t)kBuffers * rows; ++br)
+        for (int t = 0; t < nt; ++t)
+            for (int h = 0; h < 2; ++h) {
+                const int wave = t / 64, lane = t % 64, vw = wave + h * nw;
+                const int gl = vw == 0 ? lane : kFirst + kInner * (vw - 1) + (lane - GH);
+                const bool ghost = vw == 0 ? (nvw > 1 && lane >= 64 - GH) : (lane < GH || (lane >= 64 - GH && vw < nvw - 1));
+                if (vw >= nvw || ghost || gl >= nl) continue;
+                const uint32_t* d = raw + (br * nt + t) * 4;
+                uint8_t* o = out + br * sweep_w + gl * PXL;
+                for (int k = 0; k < 4; ++k) { o[2 * k] = (uint8_t)(d[k] >> (16 * h)); o[2 * k + 1] = (uint8_t)(d[k] >> (16 * h + 8)); }
+            }
+}
 
 template <int MODE>
 static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)

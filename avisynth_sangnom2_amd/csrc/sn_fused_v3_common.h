@@ -1,0 +1,102 @@
+// sn_fused_v3_common.h -- definitions shared by the fused sweep kernels (sn_fused_u8_v3.hip: two
+// 8-bit strips per register; sn_fused_u16_v3.hip: one 16-bit strip per register).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sn_internal.h"
+
+namespace sn {
+namespace v3c {
+
+constexpr int PXL = 8;           // pixels per lane and per strip
+constexpr int GH = 2;            // ghost lanes on each inner side of a strip
+constexpr int K = GH * PXL / 3;  // rows between two seam refreshes (5)
+constexpr int kFirst = 64 - GH;      // real lanes of strip 0
+constexpr int kInner = 64 - 2 * GH;  // real lanes of every later strip
+constexpr int kOutOfRange = 0x7fffffff;  // voffset that the buffer range check always rejects
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct Args {
+    const uint8_t* src;
+    uint8_t* dst;
+    int64_t src_frame_stride;
+    int64_t dst_frame_stride;
+    int32_t src_pitch;
+    int32_t dst_pitch;
+    int32_t w;
+    int32_t nk;      // kept lines
+    int32_t offset;  // first kept line in dst
+    int32_t dh;
+    int32_t thr;
+    int32_t nl;      // real lanes = w / 8
+    int32_t nvw;     // virtual wavefronts
+    int32_t nw;      // physical waves
+    int32_t src_bytes;  // bytes of one source plane (buffer descriptor range)
+    int32_t dst_bytes;  // bytes of one destination plane
+    int32_t dbg;        // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh (wrong results)
+    // pool coupling for subsampled chroma (modes kLumaSpill / kChroma, see below)
+    const uint8_t* pool_in;   // smoothed buffers left by the previous pass (kChroma)
+    uint8_t* pool_out;        // where this pass leaves its smoothed buffers (kLumaSpill, first kChroma pass)
+    int64_t pool_frame_stride;
+    int32_t pool_rows;        // rows a pool buffer holds (row index 1 .. pool_rows - 1 used)
+    int32_t rows_in;          // rows 1 .. rows_in of pool_in are valid, later rows read as zero
+    int32_t rows_out;         // rows 1 .. rows_out are written to pool_out (0 = none)
+    int32_t region_w;         // kChroma: columns < region_w belong to the chroma plane
+    int32_t sweep_rows;       // kChroma: pool rows to sweep (>= nk - 1)
+};
+
+// The reference's nine buffers are sized for the luma plane and shared by all planes, so a
+// subsampled chroma pass smooths a pool that still holds the previous pass's results outside the
+// chroma region.  Exact emulation in the fused kernel:
+//   kLumaSpill  the luma sweep also leaves its smoothed values O of the rows the chroma passes can
+//               reach in a scratch pool;
+//   kChroma     the sweep runs over the whole luma-wide pool: inside the chroma region the cost of
+//               the next row comes from the chroma lines (stage 1), elsewhere it is the previous
+//               pass's O read back from the pool; stage 3 and the output exist only inside the region.
+// Pool layout: [buffer][row][thread][4 dwords], dword k = O[2k] | O[2k+1] << 8 (packed pairs), i.e. every
+// thread re-reads what the thread with the same columns wrote; ghost lanes read their owner's slot.
+enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2 };
+
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned dpp_from_left(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned dpp_from_right(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// |a - b| in both halves (values < 32768 per half)
+__device__ __forceinline__ unsigned pk_absdiff(unsigned a, unsigned b) { return pk_max(a, b) - pk_min(a, b); }
+// (m & x) | (~m & y): v_bfi_b32
+__device__ __forceinline__ unsigned bfi(unsigned m, unsigned x, unsigned y) { return (m & x) | (~m & y); }
+
+// 16-byte buffer store with the whole offset in voffset and soffset = 0.  With an SGPR soffset hipcc pads no wait
+// state after a >8-byte store, and gfx950 was seen still reading the last data register while the next VALU
+// instruction overwrote it (stale words in the spilled rows of 3840-wide 16-bit sweeps); in this form the
+// compiler's hazard recogniser adds the s_nop itself where one is needed.  `voff` may be kOutOfRange: adding
+// an offset below 2^31 keeps it out of range.
+__device__ __forceinline__ void store_b128(const u32x4& d, __amdgpu_buffer_rsrc_t r, int voff, int off)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)((unsigned)voff + (unsigned)off), 0, 0);
+}
+
+
+inline int strips_for(int nl) { return nl <= 64 ? 1 : 1 + (nl - kFirst + kInner - 1) / kInner; }
+
+}  // namespace v3c
+}  // namespace sn

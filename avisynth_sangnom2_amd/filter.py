@@ -41,7 +41,9 @@ class ClipFormat:
 
 _FORMATS = {
     "Y8": dict(bytes=1, bits=8, planes=1), "Y10": dict(bytes=2, bits=10, planes=1),
+    "Y12": dict(bytes=2, bits=12, planes=1), "Y14": dict(bytes=2, bits=14, planes=1),
     "Y16": dict(bytes=2, bits=16, planes=1), "Y32": dict(bytes=4, bits=32, planes=1),
+    "YUV422P16": dict(bytes=2, bits=16, planes=3, subw=1, subh=0),
     "YUV420P8": dict(bytes=1, bits=8, planes=3, subw=1, subh=1),
     "YUV420P10": dict(bytes=2, bits=10, planes=3, subw=1, subh=1),
     "YUV420P16": dict(bytes=2, bits=16, planes=3, subw=1, subh=1),
@@ -131,6 +133,13 @@ class SangNom2:
         i = self.info()
         out = np.empty((9, i.pool_rows, i.pool_stride), dtype=self.clip.dtype)
         self._check(self._lib.sn_debug_read_pool(self._h, slot, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_coupled_rows(self, which: int) -> np.ndarray:
+        """Rows the fused 4:2:0 sweep of plane `which` left for the next plane: [9, rows, width]."""
+        rows = self.info().coupled_rows
+        out = np.empty((9, rows, self.clip.width), dtype=self.clip.dtype)
+        self._check(self._lib.sn_debug_read_coupled_rows(self._h, which, out.ctypes.data, out.nbytes))
         return out
 
     # -- GetFrame -------------------------------------------------------------------------------

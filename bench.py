@@ -29,6 +29,7 @@ WORKLOADS = {
     "1080p-Y8": ("Y8", 1920, 1080, dict(order=1, aa=48)),
     "4320p-Y8": ("Y8", 7680, 4320, dict(order=1, aa=48)),
     "2160p-YUV420P8": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "2160p-Y16": ("Y16", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420P16": ("YUV420P16", 3840, 2160, dict(order=1, aa=48, aac=48)),
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
 }

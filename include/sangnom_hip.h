@@ -89,7 +89,9 @@ typedef struct sn_info {
     int32_t history_free;     /* 1 if a frame's result cannot depend on earlier frames       */
     int64_t frames;           /* frames processed so far                                     */
     int64_t fused_frames;     /* ... of which by the fused kernel                            */
-    int64_t fused_tiles_rejected; /* speculative tiles whose verification failed (redone)    */
+    int32_t coupled_rows;     /* rows per buffer the fused 4:2:0 sweeps hand from plane to   *
+                               * plane (0: this configuration has no such hand-off)          */
+    int32_t reserved0;
     double  threshold[3];     /* aaf[plane] after conversion to the sample type              */
 } sn_info;
 
@@ -133,6 +135,12 @@ int sn_get_info(sn_context* ctx, sn_info* info);
 /* Test hook: copy the device scratch pool of batch slot `slot` to host memory
  * (9 x pool_rows x pool_stride elements).  Synchronises the stream. */
 int sn_debug_read_pool(sn_context* ctx, int32_t slot, void* host_dst, size_t bytes);
+
+/* Test hook for the fused 4:2:0 sweeps: the smoothed rows one plane's sweep left for the next one
+ * (which = 0: luma -> U, 1: U -> V) of batch slot 0, rearranged to 9 x coupled_rows x width samples --
+ * what rows 0..coupled_rows-1 of the reference's shared pool (src/SangNom2.cpp:322-329) hold at that
+ * point, row 0 unused.  Synchronises the stream. */
+int sn_debug_read_coupled_rows(sn_context* ctx, int32_t which, void* host_dst, size_t bytes);
 
 int sn_abi_version(void);
 

@@ -10,6 +10,7 @@ import pytest
 
 from avisynth_sangnom2_amd import ClipFormat, SangNom2, SangNomError, clip_format, synth
 from oracle.oracle import Oracle
+from oracle.sangnom_numpy import NumpySangNom
 from tests.util import describe_diff, make_frames, oracle_cfg, same
 
 pytestmark = pytest.mark.gpu
@@ -202,6 +203,25 @@ FUSED_CASES = [
 ]
 
 
+FUSED_CASES += [
+    # 9..16-bit samples: sn_fused_u16_v3.hip (one pixel per register, up to 3840 wide)
+    ("Y16", 64, 32, {}),
+    ("Y16", 512, 20, dict(order=2)),
+    ("Y16", 544, 24, dict(aa=100)),
+    ("Y10", 1024, 28, dict(aa=20)),
+    ("Y16", 1920, 24, dict(order=0)),
+    ("Y16", 3840, 26, {}),
+    ("Y16", 256, 4, {}),
+    ("Y12", 320, 40, dict(dh=True)),
+    ("YUV444P16", 576, 24, dict(aac=48)),
+    ("YUV420P16", 128, 64, dict(aac=48)),
+    ("YUV420P10", 1024, 40, dict(aac=30, order=2)),
+    ("YUV420P16", 3840, 48, dict(aac=48)),
+    ("YUV422P16", 576, 28, dict(aac=48)),
+    ("YUV420P16", 96, 8, dict(aac=48)),
+]
+
+
 @pytest.mark.parametrize("fmt,w,h,kw", FUSED_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in FUSED_CASES])
 @pytest.mark.parametrize("pattern", ["noise", "checker", "edges"])
 def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
@@ -218,7 +238,7 @@ def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
 
 
 def test_fused_not_eligible_is_reported(hip_lib):
-    for fmt, w, h, kw in (("Y16", 64, 32, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(luma=False, aac=1)),
+    for fmt, w, h, kw in (("Y32", 64, 32, {}), ("Y16", 3872, 16, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(luma=False, aac=1)),
                           ("Y8", 7712, 16, {})):
         with pytest.raises(SangNomError, match="not eligible"):
             SangNom2(clip_format(fmt, w, h), mode="fused", **kw)
@@ -299,3 +319,34 @@ def test_full_size_16bit_and_float_match_oracle(hip_lib, fmt, w, h, kw):
         got = flt.get_frame(src)
     for p in range(3):
         assert same(want[p], got[p]), f"{fmt} plane {p}: " + describe_diff(want[p], got[p])
+
+
+COUPLED = [("YUV420P8", 256, 64), ("YUV420P8", 1920, 1080), ("YUV420P8", 3840, 2160), ("YUV420P8", 7680, 360),
+           ("YUV420P10", 1920, 1080), ("YUV420P16", 640, 48), ("YUV420P16", 3840, 2160)]
+
+
+@pytest.mark.parametrize("fmt,w,h", COUPLED, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in COUPLED])
+def test_fused_420_hand_off_rows_match_the_shared_pool(hip_lib, fmt, w, h):
+    """What the luma sweep leaves for U and the U sweep for V is, sample for sample, what the reference's
+    shared pool holds at those points (src/SangNom2.cpp:322-329): the final planes alone cannot show a wrong
+    stale row whose influence stays below the aa threshold."""
+    kw = dict(aa=48, aac=48)
+    clip = clip_format(fmt, w, h)
+    src = synth.frame(clip, "noise", seed=5)
+    n = NumpySangNom(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=3, subw=1, subh=1, **kw)
+    want = []
+    for p in (0, 1):
+        d = np.zeros_like(src[p])
+        d[0::2] = src[p][0::2]     # order=1 keeps the even lines (offset 0, SangNom2.cpp:344-351)
+        n._plane(d, 0, p)
+        want.append(n.pool.copy())
+    with SangNom2(clip, mode="fused", **kw) as flt:
+        flt.get_frame(src)
+        rows = flt.info().coupled_rows
+        nr_c, bh = h // 4 - 1, (h + 1) // 2
+        assert rows == min(nr_c + 2, bh - 1) + 1
+        for which, last in ((0, rows - 1), (1, min(nr_c + 1, bh - 1))):
+            got = flt.read_coupled_rows(which)[:, 1:last + 1].astype(np.int64)
+            exp = want[which][:, 1:last + 1, :w]
+            bad = np.argwhere(got != exp)
+            assert len(bad) == 0, f"hand-off {which}: {len(bad)} samples differ, first (buffer,row-1,x) {bad[:4].tolist()}"
