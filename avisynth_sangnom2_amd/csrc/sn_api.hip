@@ -31,8 +31,10 @@ struct Context {
     bool history_free = false;
     bool use_fused = false;
 
-    PoolArgs pool{};
-    int slots = 1;
+    PoolArgs pool{};  // allocated on first use when the fused kernels serve the configuration
+    int slots = 1;    // frames of a batch the pool path runs at once (1: frames in order on slot 0)
+
+    int fslots = 1;   // frames per chunk of the fused 4:2:0 sweeps (each needs its two hand-off pools)
 
     // fused 8-bit path with subsampled chroma: two scratch pools per batch slot (sn_fused_u8_v3.hip, Mode)
     bool fused420 = false;
@@ -174,6 +176,23 @@ void sn_destroy(sn_context* h)
     delete c;
 }
 
+// Device scratch one context may hold per kind (pool-path slots; hand-off pools of the fused 4:2:0 sweeps).
+// SN_SCRATCH_BUDGET_MB overrides it (the tests use that to exercise the chunking on small batches).
+static int64_t scratch_budget()
+{
+    const char* e = getenv("SN_SCRATCH_BUDGET_MB");
+    return e && atoll(e) > 0 ? atoll(e) << 20 : 24ll << 30;
+}
+
+// The pool: zero-filled (the convention that makes the reference's output defined).
+static int ensure_pool(Context* c)
+{
+    if (c->pool.base) return SN_OK;
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->pool.base), (size_t)c->pool.slot_bytes * c->slots));
+    SN_HIP(c, hipMemsetAsync(c->pool.base, 0, (size_t)c->pool.slot_bytes * c->slots, c->stream));
+    return SN_OK;
+}
+
 static int create_impl(const sn_config* cfg, Context* c)
 {
     c->cfg = *cfg;
@@ -202,7 +221,6 @@ static int create_impl(const sn_config* cfg, Context* c)
     if (c->out_height / 2 > 65535)
         return sn::fail(c, SN_ERR_UNSUPPORTED, "height %d exceeds the supported maximum", cfg->height);
     c->history_free = sn::compute_history_free(*c);
-    c->slots = c->history_free ? c->cfg.max_batch : 1;
 
     const bool eligible = sn::fused_eligible(c->cfg);
     if (cfg->mode == SN_MODE_FUSED && !eligible)
@@ -217,13 +235,22 @@ static int create_impl(const sn_config* cfg, Context* c)
         c->own_stream = true;
     }
 
-    // the pool: zero-filled (the convention that makes the reference's output defined)
+    // Scratch is bounded: a batch larger than what scratch_budget() holds runs in chunks on the same slots
+    // (only history-free configurations batch at all, and for them a slot's old content never matters).
     c->pool.stride_e = c->stride_e;
     c->pool.bh = c->bh;
     c->pool.slot_bytes = (int64_t)sn::kBuffers * (c->bh + 1) * c->stride_e * cfg->bytes_per_sample;
     c->pool.slot_bytes = (c->pool.slot_bytes + 255) & ~(int64_t)255;
-    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->pool.base), (size_t)c->pool.slot_bytes * c->slots));
-    SN_HIP(c, hipMemsetAsync(c->pool.base, 0, (size_t)c->pool.slot_bytes * c->slots, c->stream));
+    int rc = SN_OK;
+    auto fit = [&](int64_t per_frame) {
+        const int64_t n = scratch_budget() / per_frame;
+        return (int)(n < 1 ? 1 : n < c->cfg.max_batch ? n : c->cfg.max_batch);
+    };
+    c->slots = c->history_free ? fit(c->pool.slot_bytes) : 1;
+    if (!c->use_fused) {
+        rc = ensure_pool(c);
+        if (rc != SN_OK) return rc;
+    }
     if (c->fused420) {
         // rows the chroma sweeps can reach: 1 .. min(nr_c + 2, bh - 1), plus row 0
         const int nr_c = c->plane_h_out(1) / 2 - 1;
@@ -231,11 +258,14 @@ static int create_impl(const sn_config* cfg, Context* c)
         c->fpool_rows = reach + 1;
         c->fpool_frame_bytes = cfg->bytes_per_sample == 2 ? sn::fused_u16_pool_bytes(cfg->width, c->fpool_rows)
                                                           : sn::fused_v3_pool_bytes(cfg->width, c->fpool_rows);
+        c->fslots = fit(2 * c->fpool_frame_bytes);  // fused420 implies history-free (fused_eligible)
+        // a chunk is three launches of one workgroup per frame: whole rounds of resident workgroups
+        // (two waves per SIMD, 256 CUs) leave no partly filled round at the end of each launch
+        const int nw = cfg->bytes_per_sample == 2 ? sn::fused_u16_waves(cfg->width) : sn::fused_v3_waves(cfg->width);
+        const int round = 256 * (8 / nw);
+        if (c->fslots > round) c->fslots -= c->fslots % round;
         for (int i = 0; i < 2; ++i)
-        {
-            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->slots));
-            if (const char* e = getenv("SN_DEBUG_FILL")) SN_HIP(c, hipMemset(c->fpool[i], atoi(e), (size_t)c->fpool_frame_bytes * c->slots));
-        }
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->fslots));
     }
     SN_HIP(c, hipStreamSynchronize(c->stream));
     return SN_OK;
@@ -290,8 +320,11 @@ static int check_planes(Context* c, const void* const src[3], const int32_t sp[3
 static int run_group(Context* c, int n, const void* const src[3], const int64_t sfs[3], const int32_t sp[3],
                      void* const dst[3], const int64_t dfs[3], const int32_t dp[3], int f0, int offset)
 {
+    sn::PlaneArgs pa[3];
+    bool fused[3] = {false, false, false};
     for (int p = 0; p < c->nplanes(); ++p) {
-        sn::PlaneArgs a{};
+        sn::PlaneArgs& a = pa[p];
+        a = sn::PlaneArgs{};
         a.src = static_cast<const uint8_t*>(src[p]) + (int64_t)f0 * sfs[p];
         a.dst = static_cast<uint8_t*>(dst[p]) + (int64_t)f0 * dfs[p];
         a.src_frame_stride = sfs[p];
@@ -304,13 +337,26 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
         a.offset = offset;
         a.dh = c->cfg.dh;
         a.enabled = (c->cfg.dh || c->process[p]) ? 1 : 0;
-        if (a.enabled && c->use_fused && sn::fused_layout_ok(a)) {
-            // SN_FUSED_VER=2 selects the previous formulation (sn_fused_u8.hip) for A/B runs
-            static const int ver = [] { const char* e = getenv("SN_FUSED_VER"); return e ? atoi(e) : 3; }();
-            if (c->fused420) {
-                // luma sweep leaves its smoothed rows in pool 0; U reads pool 0 and leaves pool 1; V reads pool 1
-                const int nr_c = c->plane_h_out(1) / 2 - 1;
-                const int reach = c->fpool_rows - 1;
+        fused[p] = a.enabled && c->use_fused && sn::fused_layout_ok(a);
+    }
+    auto frames_from = [](sn::PlaneArgs a, int i) {
+        a.src += (int64_t)i * a.src_frame_stride;
+        a.dst += (int64_t)i * a.dst_frame_stride;
+        return a;
+    };
+    // SN_FUSED_VER=2 selects the previous formulation (sn_fused_u8.hip) for A/B runs
+    static const int ver = [] { const char* e = getenv("SN_FUSED_VER"); return e ? atoi(e) : 3; }();
+
+    // Fused 4:2:0: the luma sweep leaves its smoothed rows in hand-off pool 0, U reads pool 0 and leaves pool 1,
+    // V reads pool 1 -- so the three sweeps of a chunk of frames run back to back on that chunk's pools.
+    const bool coupled = c->fused420 && fused[0] && fused[1] && fused[2];
+    if (coupled) {
+        const int nr_c = c->plane_h_out(1) / 2 - 1;
+        const int reach = c->fpool_rows - 1;
+        const int sweep_u = nr_c + 1 < c->bh - 1 ? nr_c + 1 : c->bh - 1;
+        for (int i = 0; i < n; i += c->fslots) {
+            const int m = n - i < c->fslots ? n - i : c->fslots;
+            for (int p = 0; p < 3; ++p) {
                 sn::FusedPool fp{};
                 fp.sweep_w = c->cfg.width;
                 fp.frame_stride = c->fpool_frame_bytes;
@@ -323,26 +369,47 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
                     fp.mode = 2;
                     fp.pool_in = c->fpool[p - 1];
                     fp.pool_out = p == 1 ? c->fpool[1] : nullptr;
-                    const int sweep_u = nr_c + 1 < c->bh - 1 ? nr_c + 1 : c->bh - 1;
                     fp.rows_in = p == 1 ? reach : sweep_u;
                     fp.sweep_rows = p == 1 ? sweep_u : nr_c;
                     fp.rows_out = p == 1 ? sweep_u : 0;
                 }
-                if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, &fp));
-                else SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, &fp));
-            } else if (c->cfg.bytes_per_sample == 2) {
-                SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, nullptr));
-            } else if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w)) {
-                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, nullptr));
-            } else {
-                SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));
+                const sn::PlaneArgs a = frames_from(pa[p], i);
+                if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), m, &fp));
+                else SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), m, &fp));
             }
-            if (p == 0 || !(c->cfg.dh || c->process[0])) c->fused_frames += n;
+        }
+        c->fused_frames += n;
+        return SN_OK;
+    }
+
+    bool counted = false, pool_path = false;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        const sn::PlaneArgs& a = pa[p];
+        if (fused[p] && !c->fused420) {
+            if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, nullptr));
+            else if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w))
+                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, nullptr));
+            else SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));
+            if (!counted) c->fused_frames += n;
+            counted = true;
             continue;
         }
         SN_HIP(c, sn::launch_assemble(c->stream, a, c->cfg.bytes_per_sample, n));
-        if (!a.enabled) continue;
-        SN_HIP(c, sn::launch_pool_plane(c->stream, a, c->pool, c->cfg.bytes_per_sample, c->threshold(p), n, 0));
+        pool_path = pool_path || a.enabled;
+    }
+    if (!pool_path) return SN_OK;
+    // Pool path, a chunk of frames at a time on the chunk's slots; within a chunk the planes run in the
+    // reference's order, because with subsampled chroma a frame's chroma result depends on what its own luma
+    // pass left in the slot (SangNom2.cpp:322-329).
+    int rc = ensure_pool(c);
+    if (rc != SN_OK) return rc;
+    for (int i = 0; i < n; i += c->slots) {
+        const int m = n - i < c->slots ? n - i : c->slots;
+        for (int p = 0; p < c->nplanes(); ++p) {
+            if (!pa[p].enabled || (fused[p] && !c->fused420)) continue;
+            SN_HIP(c, sn::launch_pool_plane(c->stream, frames_from(pa[p], i), c->pool, c->cfg.bytes_per_sample,
+                                            c->threshold(p), m, 0));
+        }
     }
     return SN_OK;
 }
@@ -457,6 +524,7 @@ int sn_debug_read_pool(sn_context* h, int32_t slot, void* host_dst, size_t bytes
     Context* c = reinterpret_cast<Context*>(h);
     if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
     const size_t need = (size_t)sn::kBuffers * (c->bh + 1) * c->stride_e * c->cfg.bytes_per_sample;
+    if (!c->pool.base) return sn::fail(c, SN_ERR_INVALID_ARG, "sn_debug_read_pool: the pool path has not run on this context");
     if (!host_dst || bytes < need || slot < 0 || slot >= c->slots)
         return sn::fail(c, SN_ERR_INVALID_ARG, "sn_debug_read_pool: bad slot or buffer too small (%zu needed)", need);
     SN_HIP(c, hipSetDevice(c->device));

@@ -196,9 +196,10 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
     else box7<false>(S, Bx, role);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        O[j] = (Bx[j] >> 4) & kVal;  // (sum / 16) wraps to uint16_t, SangNom2.cpp:152
+        const unsigned t = Bx[j] & 0xffff0u;  // O << 4; shared by O and the key: three full-rate ops
+        O[j] = t >> 4;                        // (sum / 16) wraps to uint16_t, SangNom2.cpp:152
         A[j] = O[j] + D[j];
-        kmin[j] = umin(kmin[j], (Bx[j] & 0xffff0u) | rank_of<BUF>());  // (O << 4) | rank
+        kmin[j] = umin(kmin[j], t | rank_of<BUF>());
     }
     if constexpr (MODE != kPlain) io.store(BUF, rc.r, rc.vout, O);
 }

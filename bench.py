@@ -141,9 +141,19 @@ def main():
     clip = clip_format(fmt, w, h)
     frame_in_bytes = sum((h >> (clip.subh if p else 0)) * (w >> (clip.subw if p else 0)) * clip.bytes
                          for p in range(min(clip.planes, 3)))
-    # Ring of distinct frames larger than the 256 MiB Infinity Cache (in + out), SURVEY.md 7-H7.
-    # One fused-kernel workgroup (4 waves) sweeps one plane and two fit a CU, so 512 frames fill the chip.
-    batch = args.batch or max(64, min(512, (6 << 30) // frame_in_bytes))
+    # Ring of distinct frames far larger than the 256 MiB Infinity Cache (in + out), SURVEY.md 7-H7.
+    # One fused-kernel workgroup sweeps one plane of one frame; 2048 waves are resident at a time (two per
+    # SIMD), and a launch is sized to four such rounds so that uneven workgroup durations even out instead
+    # of leaving SIMDs idle at the end of a single round.  Capped at 48 GiB of in + out.
+    strips = 1 if w <= 512 else 1 + -(-(w // 8 - 62) // 60)
+    waves_per_frame = strips if clip.bytes == 2 else (strips + 1) // 2
+    out_bytes = frame_in_bytes * (2 if kw.get("dh") else 1)
+    per_round = 256 * (8 // waves_per_frame)        # workgroups resident at a time
+    fit = (48 << 30) // (frame_in_bytes + out_bytes)
+    if clip.planes >= 3 and clip.subw + clip.subh > 0:  # the 4:2:0 sweeps also need 2 hand-off pools per frame
+        fit = min(fit, (24 << 30) // (2 * 9 * (h // 4 + 3) * waves_per_frame * 64 * 16))
+    rounds = max(1, min(4, fit // per_round))
+    batch = args.batch or (rounds * per_round if clip.bytes < 4 else 128)
     stream = torch.cuda.Stream(dev)  # a real (non-null) HIP stream shared with the context, so that
     # torch.cuda.Event timing below sees exactly the kernels the library launches
     flt = SangNom2(clip, device=local_rank, max_batch=batch, mode=args.mode, stream=stream.cuda_stream, **kw)

@@ -350,3 +350,30 @@ def test_fused_420_hand_off_rows_match_the_shared_pool(hip_lib, fmt, w, h):
             exp = want[which][:, 1:last + 1, :w]
             bad = np.argwhere(got != exp)
             assert len(bad) == 0, f"hand-off {which}: {len(bad)} samples differ, first (buffer,row-1,x) {bad[:4].tolist()}"
+
+
+@pytest.mark.parametrize("fmt,mode", [("YUV420P8", "fused"), ("YUV420P16", "fused"), ("YUV420P8", "pool"), ("Y16", "pool")])
+def test_batch_larger_than_the_scratch_budget_runs_in_chunks(hip_lib, monkeypatch, fmt, mode):
+    """Scratch is bounded (SN_SCRATCH_BUDGET_MB): a bigger batch is run in chunks on the same slots."""
+    import torch
+    monkeypatch.setenv("SN_SCRATCH_BUDGET_MB", "1")
+    clip = clip_format(fmt, 256, 64)
+    kw = dict(aa=48, aac=48)
+    N = 31
+    frames = make_frames(clip, "noise", N, seed0=3)
+    dev = torch.device("cuda:0")
+    tdt = {np.uint8: torch.uint8, np.uint16: torch.int16}[clip.dtype]
+    with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(np.int16 if clip.bytes == 2 else np.uint8)).to(dev)
+               for p in range(clip.planes)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
+        torch.cuda.synchronize()
+        flt.process_batch(src, dst)
+        flt.synchronize()
+        want_fused = N if mode == "fused" else 0
+        assert flt.info().fused_frames == want_fused
+    for f in range(N):
+        want = Oracle(oracle_cfg(clip, **kw)).process(frames[f])
+        for p in range(clip.planes):
+            got = dst[p][f].cpu().numpy().view(clip.dtype)
+            assert same(want[p], got), f"frame {f} plane {p}: " + describe_diff(want[p], got)
