@@ -478,9 +478,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u16_v3(Args a)
     const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
 
     Out pending{};
+    TurnTaking turns;
+    turns.init(a.turn_shift);
     auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
         constexpr bool S1 = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
+        turns.update();
         Raw qnext = qn;
         if constexpr (S1) {
             unpack(nn, qn, role);  // waits for the line prefetched one row ago
@@ -627,6 +630,7 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.nl = a.w / v3c::PXL;
     a.nvw = v3c::strips_for(a.nl);
     a.nw = a.nvw;
+    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw);
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
     if (!pool) return w16::launch_mode<v3c::kPlain>(st, a, nframes);

@@ -617,9 +617,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_v3(Args a)
     Out pending{};
     // One pool row r: n = K[r], nn = K[r+1] (S1: the pair exists), c = K[r-1] parked (S3: the row has an
     // interpolated line).
+    TurnTaking turns;
+    turns.init(a.turn_shift);
     auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
         constexpr bool HAS_NEXT = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
+        turns.update();
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
             unpack(nn, qn, role);  // waits for the line prefetched one row ago
@@ -796,6 +799,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
     static const int dbg = [] { const char* e = getenv("SN_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
+    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw);
     if (!pool) return launch_mode<v3::kPlain>(st, a, nframes);
     a.pool_in = pool->pool_in;
     a.pool_out = pool->pool_out;

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sn_internal.h"
 
@@ -47,6 +48,7 @@ struct Args {
     int32_t rows_out;         // rows 1 .. rows_out are written to pool_out (0 = none)
     int32_t region_w;         // kChroma: columns < region_w belong to the chroma plane
     int32_t sweep_rows;       // kChroma: pool rows to sweep (>= nk - 1)
+    int32_t turn_shift;       // log2 of the priority time slice in 100 MHz ticks (TurnTaking)
 };
 
 // The reference's nine buffers are sized for the luma plane and shared by all planes, so a
@@ -84,6 +86,45 @@ __device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
 __device__ __forceinline__ unsigned pk_absdiff(unsigned a, unsigned b) { return pk_max(a, b) - pk_min(a, b); }
 // (m & x) | (~m & y): v_bfi_b32
 __device__ __forceinline__ unsigned bfi(unsigned m, unsigned x, unsigned y) { return (m & x) | (~m & y); }
+
+// Two workgroups share every SIMD (one wave each), and the issue arbiter serves equal priorities oldest first:
+// left alone, the wave dispatched first runs at nearly its solo speed and the other one on the leftovers, so the
+// first finishes a 2160p sweep after 3.6 ms and the second only after 5.7 ms -- the last 2.1 ms with one wave per
+// SIMD (measured with per-wave timestamps; MI355X_MICROARCH.md, "Two waves per SIMD", item 2).  Taking turns at
+// s_setprio 1 in slices of the free-running 100 MHz clock, the wave in the odd hardware slot during odd slices
+// and vice versa, makes both advance at the same average rate and finish together.  Slices of about a quarter
+// of a sweep measured best (short ones cost throughput); the slice length comes from the host.
+struct TurnTaking {
+    unsigned slot_parity;
+    int shift;
+    __device__ __forceinline__ void init(int turn_shift)
+    {
+        slot_parity = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u;  // HW_REG_HW_ID, wave_id bit 0
+        shift = turn_shift;
+    }
+    __device__ __forceinline__ void update() const  // once per row: a few scalar instructions
+    {
+        if (shift == 0) return;
+        const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> shift) & 1u;
+        if (turn != slot_parity) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+};
+
+// slice = about a quarter of the time a sweep of nk kept lines takes (a row costs roughly 4.5 us).  Only for
+// workgroups of four waves: those put one wave on each SIMD, two workgroups fill a CU, and the partners on all four
+// SIMDs are the same two workgroups in opposite slots.  With other shapes the waves of a workgroup -- tied to each
+// other by the seam refresh -- would hold different priorities at the same time (2-wave workgroups lost 8 % with
+// turns), and an 8-wave workgroup has both waves of every SIMD itself (they cannot drift apart; turns cost 1 %).
+inline int turn_shift_for(int nk, int waves)
+{
+    static const int forced = [] { const char* e = getenv("SN_TURN_SHIFT"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    if (waves != 4) return 0;
+    int s = 10;
+    while ((128ll * nk) >> (s + 1)) ++s;
+    return s;
+}
 
 // 16-byte buffer store with the whole offset in voffset and soffset = 0.  With an SGPR soffset hipcc pads no wait
 // state after a >8-byte store, and gfx950 was seen still reading the last data register while the next VALU
