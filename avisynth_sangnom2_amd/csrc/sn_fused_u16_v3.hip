@@ -330,20 +330,24 @@ __host__ __device__ constexpr int lds_bytes(int nw, int mode)
 }
 
 template <int NW, int MODE>
-__global__ void __launch_bounds__(NW * 64, 2) k_fused_u16_v3(Args a)
+__global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int RB = reg_buffers(MODE);
     constexpr int NT = NW * 64;
-    const int f = blockIdx.x;
-    const int tid = threadIdx.x;
+    // group_of(NW) frames per workgroup, each on its own NW waves and its own slice of the LDS; a frame index
+    // past the end repeats the last frame (same inputs, same outputs: harmless, and the barrier counts agree)
+    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / (NW * 64);
+    const int f_raw = (int)blockIdx.x * group_of(NW) + sub;
+    const int f = f_raw < a.nframes ? f_raw : a.nframes - 1;
+    const int tid = (int)threadIdx.x - sub * (NW * 64);
     Parked<NT, RB> parked;
-    parked.v = reinterpret_cast<uint4*>(lds_raw);
+    parked.v = reinterpret_cast<uint4*>(lds_raw + sub * lds_bytes(NW, MODE));
     parked.a = parked.v + 6 * NT;
     Mailbox<NW> mb;
     mb.h = reinterpret_cast<unsigned*>(parked.a + (kBuffers - RB) * 2 * NT);
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
 
     // lane -> column group: wave 0 owns lanes 0..61 (all 64 if it is the only wave), later waves own
     // lanes 2..61 (the last one up to 63); the other lanes are ghosts of the neighbouring wave
@@ -566,13 +570,14 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u16_v3(Args a)
 template <int MODE>
 static hipError_t launch_mode(hipStream_t st, const Args& a, int nframes)
 {
-    const int lds = lds_bytes(a.nw, MODE);
+    const int g = v3c::group_of(a.nw);
+    const int lds = lds_bytes(a.nw, MODE) * g;
     hipError_t e = hipSuccess;
 #define SN_LAUNCH(NW)                                                                                              \
     case NW:                                                                                                       \
         if (lds > 64 * 1024)                                                                                       \
             e = hipFuncSetAttribute((const void*)k_fused_u16_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((k_fused_u16_v3<NW, MODE>), dim3(nframes), dim3(NW * 64), lds, st, a); \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_fused_u16_v3<NW, MODE>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a); \
         break;
     switch (a.nw) {
         SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
@@ -630,7 +635,8 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.nl = a.w / v3c::PXL;
     a.nvw = v3c::strips_for(a.nl);
     a.nw = a.nvw;
-    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw);
+    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
+    a.nframes = nframes;
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
     if (!pool) return w16::launch_mode<v3c::kPlain>(st, a, nframes);

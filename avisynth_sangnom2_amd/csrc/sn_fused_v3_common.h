@@ -49,6 +49,7 @@ struct Args {
     int32_t region_w;         // kChroma: columns < region_w belong to the chroma plane
     int32_t sweep_rows;       // kChroma: pool rows to sweep (>= nk - 1)
     int32_t turn_shift;       // log2 of the priority time slice in 100 MHz ticks (TurnTaking)
+    int32_t nframes;          // frames of this launch (the last workgroup may hold fewer than group_of(nw))
 };
 
 // The reference's nine buffers are sized for the luma plane and shared by all planes, so a
@@ -110,6 +111,11 @@ struct TurnTaking {
         else __builtin_amdgcn_s_setprio(0);
     }
 };
+
+// Frames per workgroup.  A plane that needs only one or two waves shares its workgroup with other frames' planes so
+// that every workgroup has four waves, one per SIMD (TurnTaking below relies on that shape).  The frames of a
+// workgroup are independent: each has its own slice of the dynamic LDS and they only meet at the barriers.
+__host__ __device__ constexpr int group_of(int nw) { return nw == 1 ? 4 : nw == 2 ? 2 : 1; }
 
 // slice = about a quarter of the time a sweep of nk kept lines takes (a row costs roughly 4.5 us).  Only for
 // workgroups of four waves: those put one wave on each SIMD, two workgroups fill a CU, and the partners on all four
