@@ -49,23 +49,24 @@ def algorithmic_bytes_per_frame(clip, flt, kw) -> int:
 
 
 def recorded_traffic(workload: str, batch: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.csv:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950 coalesced reads).  Only valid for the configuration the
-    passes were run on; None otherwise (the counters cannot be read from inside this process)."""
-    if workload != "2160p-Y8" or batch != 512:
-        return None
-    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.csv")
-    if not os.path.exists(path):
-        return None
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.csv, made by
+    tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 coalesced reads).  Only valid for the workload and
+    batch the passes were run on (profiles/r1_bench.json); None otherwise -- the counters cannot be read
+    from inside this process."""
     import csv
-    vals = {}
-    for row in csv.DictReader(open(path)):
-        if row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals[row["counter"]] = float(row["sum_over_dims"])  # last dispatch wins
-    if len(vals) != 2:
+    import json
+    try:
+        ref = json.loads(open(os.path.join(ROOT, "profiles", "r1_bench.json")).read().strip().splitlines()[-1])
+        if not ref["config"]["workload"].startswith(workload + " ") or ref["config"]["frames_per_step_per_gpu"] != batch:
+            return None
+        vals = {}
+        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.csv"))):
+            if row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[row["counter"]] = float(row["sum_over_dims"])  # last dispatch wins
+        return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    except (OSError, KeyError, ValueError, IndexError):
         return None
-    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 
 
 def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
