@@ -386,7 +386,8 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
     for (int p = 0; p < c->nplanes(); ++p) {
         const sn::PlaneArgs& a = pa[p];
         if (fused[p] && !c->fused420) {
-            if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, nullptr));
+            if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(c->stream, a, c->threshold(p), n));
+            else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, nullptr));
             else if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w))
                 SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, nullptr));
             else SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));

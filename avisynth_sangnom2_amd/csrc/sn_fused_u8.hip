@@ -538,7 +538,7 @@ bool fused_eligible(const sn_config& c)
     } else if (c.bytes_per_sample == 1) {
         if (!fused_v3_plane_ok(c.width) && !fused_v2_plane_ok(c.width)) return false;
     } else {
-        return false;
+        return fused_f32_plane_ok(c.width) && !chroma_subsampled_and_processed(c);
     }
     if (chroma_subsampled_and_processed(c)) {
         if (!(c.dh || c.luma)) return false;

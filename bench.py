@@ -32,6 +32,7 @@ WORKLOADS = {
     "2160p-Y16": ("Y16", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420P16": ("YUV420P16", 3840, 2160, dict(order=1, aa=48, aac=48)),
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
+    "2160p-Y32": ("Y32", 3840, 2160, dict(order=1, aa=48)),
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
@@ -147,14 +148,14 @@ def main():
     # SIMD), and a launch is sized to four such rounds so that uneven workgroup durations even out instead
     # of leaving SIMDs idle at the end of a single round.  Capped at 48 GiB of in + out.
     strips = 1 if w <= 512 else 1 + -(-(w // 8 - 62) // 60)
-    waves_per_frame = strips if clip.bytes == 2 else (strips + 1) // 2
+    waves_per_frame = strips if clip.bytes >= 2 else (strips + 1) // 2
     out_bytes = frame_in_bytes * (2 if kw.get("dh") else 1)
     per_round = 256 * (8 // waves_per_frame)        # workgroups resident at a time
     fit = (48 << 30) // (frame_in_bytes + out_bytes)
     if clip.planes >= 3 and clip.subw + clip.subh > 0:  # the 4:2:0 sweeps also need 2 hand-off pools per frame
         fit = min(fit, (24 << 30) // (2 * 9 * (h // 4 + 3) * waves_per_frame * 64 * 16))
     rounds = max(1, min(4, fit // per_round))
-    batch = args.batch or (rounds * per_round if clip.bytes < 4 else 128)
+    batch = args.batch or rounds * per_round
     stream = torch.cuda.Stream(dev)  # a real (non-null) HIP stream shared with the context, so that
     # torch.cuda.Event timing below sees exactly the kernels the library launches
     flt = SangNom2(clip, device=local_rank, max_batch=batch, mode=args.mode, stream=stream.cuda_stream, **kw)

@@ -222,6 +222,26 @@ FUSED_CASES += [
 ]
 
 
+FUSED_CASES += [
+    # float samples: sn_fused_f32_v3.hip (bit patterns must agree; no subsampled chroma)
+    ("Y32", 64, 32, {}),
+    ("Y32", 512, 20, dict(order=2)),
+    ("Y32", 544, 24, dict(aa=100)),
+    ("Y32", 1024, 28, dict(aa=20)),
+    ("Y32", 1536, 30, {}),
+    ("Y32", 1920, 24, dict(order=0)),
+    ("Y32", 2880, 22, {}),
+    ("Y32", 3840, 26, {}),
+    ("Y32", 3840, 44, dict(order=2, aa=5)),
+    ("Y32", 256, 4, {}),
+    ("Y32", 256, 2, {}),
+    ("Y32", 320, 40, dict(dh=True)),
+    ("YUV444PS", 576, 24, dict(aac=48)),
+    ("YUV444PS", 64, 24, dict(dh=True, aac=48)),
+    ("YUV420PS", 128, 32, dict(chroma=False)),
+]
+
+
 @pytest.mark.parametrize("fmt,w,h,kw", FUSED_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in FUSED_CASES])
 @pytest.mark.parametrize("pattern", ["noise", "checker", "edges"])
 def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
@@ -238,7 +258,7 @@ def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
 
 
 def test_fused_not_eligible_is_reported(hip_lib):
-    for fmt, w, h, kw in (("Y32", 64, 32, {}), ("Y16", 3872, 16, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(luma=False, aac=1)),
+    for fmt, w, h, kw in (("YUV420PS", 64, 32, dict(aac=48)), ("Y32", 3872, 16, {}), ("Y16", 3872, 16, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(luma=False, aac=1)),
                           ("Y8", 7712, 16, {})):
         with pytest.raises(SangNomError, match="not eligible"):
             SangNom2(clip_format(fmt, w, h), mode="fused", **kw)
