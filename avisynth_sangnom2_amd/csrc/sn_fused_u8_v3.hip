@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         }
         const int par = (r / K) & 1;
         if (r > 1 && (r - 1) % K == 0 && !(a.dbg & 1)) {
-            __syncthreads();
+            if (!(a.dbg & 4)) __syncthreads();
             if (recv_left || recv_right) {
                 const unsigned* from = reinterpret_cast<const unsigned*>(mb.at(par, wave, recv_left ? 0 : 1, slot));
                 auto merge = [&](int b, unsigned (&Ab)[PXL]) {
