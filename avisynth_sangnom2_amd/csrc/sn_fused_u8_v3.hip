@@ -671,30 +671,42 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             if (r % K == 0 && !(a.dbg & 1)) {
                 const int wpar = ((r + 1) / K) & 1;
                 if (pub_right || pub_left) {
-                    // where my two halves go (see Mailbox): entry + position (0 = low half, 1 = high half);
-                    // halves without a neighbour land in the spare entry `NW`
-                    unsigned short *to_lo, *to_hi;  // destinations of my low / high half
-                    if (pub_right) {
-                        to_lo = wave < NW - 1 ? mb.at(wpar, wave + 1, 0, slot) : mb.at(wpar, 0, 0, slot) + 1;
-                        to_hi = wave < NW - 1 ? mb.at(wpar, wave + 1, 0, slot) + 1 : mb.at(wpar, NW, 0, slot);
-                    } else {
-                        to_lo = wave > 0 ? mb.at(wpar, wave - 1, 1, slot) : mb.at(wpar, NW, 1, slot);
-                        to_hi = wave > 0 ? mb.at(wpar, wave - 1, 1, slot) + 1 : mb.at(wpar, NW - 1, 1, slot);
-                    }
-                    auto send = [&](int b, const unsigned (&Ab)[PXL]) {
+                    // Inside the plane both halves of a seam register go to the same ghost lane of the neighbouring
+                    // wave (see Mailbox), i.e. the register is published whole, 16 bytes per store.  Only at the
+                    // wrap seam (strip NW-1 | strip NW) a half crosses over into the other half of its receiver
+                    // and is written on its own; halves at the image edge have no receiver at all.
+                    const bool whole = pub_right ? wave < NW - 1 : wave > 0;
+                    if (whole) {
+                        uint4* to = reinterpret_cast<uint4*>(pub_right ? mb.at(wpar, wave + 1, 0, slot) : mb.at(wpar, wave - 1, 1, slot));
+                        auto send = [&](int b, const unsigned (&Ab)[PXL]) {
+                            to[b * 2 + 0] = make_uint4(Ab[0], Ab[1], Ab[2], Ab[3]);
+                            to[b * 2 + 1] = make_uint4(Ab[4], Ab[5], Ab[6], Ab[7]);
+                        };
 #pragma unroll
-                        for (int j = 0; j < PXL; ++j) {
-                            to_lo[(b * PXL + j) * 2] = (unsigned short)(Ab[j] & 0xffffu);
-                            to_hi[(b * PXL + j) * 2] = (unsigned short)(Ab[j] >> 16);
+                        for (int b = 0; b < kRegBuffers; ++b) send(b, A[b]);
+#pragma unroll
+                        for (int b = kRegBuffers; b < kBuffers; ++b) {
+                            unsigned t[PXL];
+                            load_A(parked, tid, b, t);
+                            send(b, t);
                         }
-                    };
+                    } else {
+                        // wave NW-1, right seam lanes: low half (strip NW-1) -> high half of wave 0's left ghosts;
+                        // wave 0, left seam lanes: high half (strip NW) -> low half of wave NW-1's right ghosts
+                        unsigned short* to = pub_right ? mb.at(wpar, 0, 0, slot) + 1 : mb.at(wpar, NW - 1, 1, slot);
+                        const int sh = pub_right ? 0 : 16;
+                        auto send = [&](int b, const unsigned (&Ab)[PXL]) {
 #pragma unroll
-                    for (int b = 0; b < kRegBuffers; ++b) send(b, A[b]);
+                            for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * 2] = (unsigned short)(Ab[j] >> sh);
+                        };
 #pragma unroll
-                    for (int b = kRegBuffers; b < kBuffers; ++b) {
-                        unsigned t[PXL];
-                        load_A(parked, tid, b, t);
-                        send(b, t);
+                        for (int b = 0; b < kRegBuffers; ++b) send(b, A[b]);
+#pragma unroll
+                        for (int b = kRegBuffers; b < kBuffers; ++b) {
+                            unsigned t[PXL];
+                            load_A(parked, tid, b, t);
+                            send(b, t);
+                        }
                     }
                 }
             }
