@@ -402,14 +402,14 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 }
 
 // LDS mailbox, receiver-ready: word [refresh parity][wave W][side][slot][i] is what ghost lane
-// `slot` on that side of wave W loads into packed A register i -- its low half written by one
-// publisher, its high half by another (16-bit LDS stores), so receiving costs no shuffling:
+// `slot` on that side of wave W loads into packed A register i, so receiving costs no shuffling.  Inside the
+// plane the publisher stores its registers whole; at the wrap seam a half is stored on its own (16-bit store):
 //   left ghosts  (lanes 0, 1)   of wave W: both halves <- wave W-1 lanes 60, 61 (same half), except that the hi
 //                                          half of wave 0 (strip NW) <- wave NW-1 lanes 60, 61 lo half (strip NW-1)
 //   right ghosts (lanes 62, 63) of wave W: both halves <- wave W+1 lanes 2, 3 (same half), except that the lo
 //                                          half of wave NW-1 (strip NW-1) <- wave 0 lanes 2, 3 hi half (strip NW)
 template <int NW>
-struct Mailbox {  // [parity][wave 0..NW][side][slot][72][2 halves] 16-bit entries in dynamic LDS
+struct Mailbox {  // [parity][wave 0..NW][side][slot][72][2 halves] 16-bit entries in dynamic LDS (entry NW is unused)
     unsigned short* h;
     __device__ __forceinline__ unsigned short* at(int par, int wave, int side, int slot) const
     {
