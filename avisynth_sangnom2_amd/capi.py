@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsangnom_hip.so")
 
-SN_OK, SN_ERR_INVALID_ARG, SN_ERR_CONFIG, SN_ERR_HIP, SN_ERR_NO_DEVICE, SN_ERR_UNSUPPORTED = range(6)
+SN_OK, SN_ERR_INVALID_ARG, SN_ERR_CONFIG, SN_ERR_HIP, SN_ERR_NO_DEVICE, SN_ERR_UNSUPPORTED, SN_ERR_BUSY = range(7)
 SN_MODE_AUTO, SN_MODE_POOL, SN_MODE_FUSED = range(3)
 MODES = {"auto": SN_MODE_AUTO, "pool": SN_MODE_POOL, "fused": SN_MODE_FUSED}
 
@@ -22,6 +22,7 @@ EXPORTS = (
     "sn_abi_version", "sn_validate", "sn_create", "sn_destroy", "sn_last_error",
     "sn_process_host", "sn_process_device", "sn_process_device_strided", "sn_synchronize",
     "sn_get_stream", "sn_get_info", "sn_debug_read_pool", "sn_debug_read_coupled_rows",
+    "sn_host_slots", "sn_submit_host", "sn_collect_host",
 )
 
 
@@ -29,7 +30,7 @@ class SnConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "struct_size", "width", "height", "bytes_per_sample", "bits_per_sample", "num_planes",
         "sub_w", "sub_h", "order", "aa", "aac", "dh", "luma", "chroma", "device", "max_batch",
-        "mode", "reserved")] + [("stream", ctypes.c_void_p)]
+        "mode", "host_depth")] + [("stream", ctypes.c_void_p)]
 
 
 class SnInfo(ctypes.Structure):
@@ -90,6 +91,9 @@ def load():
     L.sn_last_error.restype = ctypes.c_char_p
     L.sn_process_host.argtypes = [vp, p3v, p3i, p3v, p3i, i32]
     L.sn_process_device.argtypes = [vp, p3v, p3i, p3v, p3i, i32]
+    L.sn_host_slots.argtypes = [vp]
+    L.sn_submit_host.argtypes = [vp, p3v, p3i, i32, ctypes.POINTER(i32)]
+    L.sn_collect_host.argtypes = [vp, i32, p3v, p3i]
     L.sn_process_device_strided.argtypes = [vp, i32, p3v, p3l, p3i, p3v, p3l, p3i, p3i]
     L.sn_synchronize.argtypes = [vp]
     L.sn_get_stream.argtypes = [vp]

@@ -42,6 +42,23 @@ struct Context {
     int64_t fpool_frame_bytes = 0;
     int fpool_rows = 0;
 
+    // the host ring (sn_submit_host / sn_collect_host): frames in flight, each on its own stream
+    struct HostSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;     // D2H of this slot's frame finished
+        hipEvent_t swept = nullptr;    // its kernels finished (orders history-carrying configurations)
+        uint8_t* pin_in[3] = {nullptr, nullptr, nullptr};
+        uint8_t* pin_out[3] = {nullptr, nullptr, nullptr};
+        uint8_t* dev_in[3] = {nullptr, nullptr, nullptr};
+        uint8_t* dev_out[3] = {nullptr, nullptr, nullptr};
+        bool busy = false;
+    };
+    std::vector<HostSlot> ring;
+    int host_depth = 0;
+    int ring_next = 0;
+    int ring_last = -1;  // slot of the latest submission (its `swept` event is what the next one waits for)
+    int ring_pitch_in[3] = {0, 0, 0}, ring_pitch_out[3] = {0, 0, 0};
+
     // staging for sn_process_host
     uint8_t* stage_src[3] = {nullptr, nullptr, nullptr};
     uint8_t* stage_dst[3] = {nullptr, nullptr, nullptr};
@@ -114,6 +131,7 @@ static const char* structural_text(const sn_config& c)
     if (c.num_planes == 3 && ((c.width & ((1 << c.sub_w) - 1)) || (c.height & ((1 << c.sub_h) - 1))))
         return "luma size must be a multiple of the chroma subsampling";
     if (c.max_batch < 0) return "max_batch must be >= 0";
+    if (c.host_depth < 0 || c.host_depth > 256) return "host_depth must be 0..256";
     if (c.mode < SN_MODE_AUTO || c.mode > SN_MODE_FUSED) return "mode must be SN_MODE_AUTO/POOL/FUSED";
     return nullptr;
 }
@@ -168,6 +186,18 @@ void sn_destroy(sn_context* h)
     if (c->pool.base) (void)hipFree(c->pool.base);
     for (int i = 0; i < 2; ++i)
         if (c->fpool[i]) (void)hipFree(c->fpool[i]);
+    for (auto& hs : c->ring) {
+        if (hs.stream) (void)hipStreamSynchronize(hs.stream);
+        for (int p = 0; p < 3; ++p) {
+            if (hs.pin_in[p]) (void)hipHostFree(hs.pin_in[p]);
+            if (hs.pin_out[p]) (void)hipHostFree(hs.pin_out[p]);
+            if (hs.dev_in[p]) (void)hipFree(hs.dev_in[p]);
+            if (hs.dev_out[p]) (void)hipFree(hs.dev_out[p]);
+        }
+        if (hs.done) (void)hipEventDestroy(hs.done);
+        if (hs.swept) (void)hipEventDestroy(hs.swept);
+        if (hs.stream) (void)hipStreamDestroy(hs.stream);
+    }
     for (int p = 0; p < 3; ++p) {
         if (c->stage_src[p]) (void)hipFree(c->stage_src[p]);
         if (c->stage_dst[p]) (void)hipFree(c->stage_dst[p]);
@@ -190,6 +220,7 @@ static int ensure_pool(Context* c)
     if (c->pool.base) return SN_OK;
     SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->pool.base), (size_t)c->pool.slot_bytes * c->slots));
     SN_HIP(c, hipMemsetAsync(c->pool.base, 0, (size_t)c->pool.slot_bytes * c->slots, c->stream));
+    SN_HIP(c, hipStreamSynchronize(c->stream));  // the first user may be a ring slot's stream
     return SN_OK;
 }
 
@@ -197,6 +228,7 @@ static int create_impl(const sn_config* cfg, Context* c)
 {
     c->cfg = *cfg;
     if (c->cfg.max_batch < 1) c->cfg.max_batch = 1;
+    c->host_depth = cfg->host_depth > 0 ? cfg->host_depth : 4;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return sn::fail(c, SN_ERR_NO_DEVICE, "no HIP device available (libsangnom_hip has no CPU fallback)");
@@ -244,7 +276,8 @@ static int create_impl(const sn_config* cfg, Context* c)
     int rc = SN_OK;
     auto fit = [&](int64_t per_frame) {
         const int64_t n = scratch_budget() / per_frame;
-        return (int)(n < 1 ? 1 : n < c->cfg.max_batch ? n : c->cfg.max_batch);
+        const int64_t want = c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth;  // frames in flight
+        return (int)(n < 1 ? 1 : n < want ? n : want);
     };
     c->slots = c->history_free ? fit(c->pool.slot_bytes) : 1;
     if (!c->use_fused) {
@@ -317,8 +350,10 @@ static int check_planes(Context* c, const void* const src[3], const int32_t sp[3
 }
 
 // Runs frames [f0, f0 + n) of a strided batch with one common field offset.
-static int run_group(Context* c, int n, const void* const src[3], const int64_t sfs[3], const int32_t sp[3],
-                     void* const dst[3], const int64_t dfs[3], const int32_t dp[3], int f0, int offset)
+// `st` is the stream to launch on and `slot0` the first scratch slot the frames may use (the batch entry points
+// pass the context's stream and slot 0, the host ring one frame on its slot's stream and scratch).
+static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* const src[3], const int64_t sfs[3],
+                     const int32_t sp[3], void* const dst[3], const int64_t dfs[3], const int32_t dp[3], int f0, int offset)
 {
     sn::PlaneArgs pa[3];
     bool fused[3] = {false, false, false};
@@ -363,19 +398,19 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
                 fp.pool_rows = c->fpool_rows;
                 if (p == 0) {
                     fp.mode = 1;
-                    fp.pool_out = c->fpool[0];
+                    fp.pool_out = c->fpool[0] + (int64_t)slot0 * c->fpool_frame_bytes;
                     fp.rows_out = reach;
                 } else {
                     fp.mode = 2;
-                    fp.pool_in = c->fpool[p - 1];
-                    fp.pool_out = p == 1 ? c->fpool[1] : nullptr;
+                    fp.pool_in = c->fpool[p - 1] + (int64_t)slot0 * c->fpool_frame_bytes;
+                    fp.pool_out = p == 1 ? c->fpool[1] + (int64_t)slot0 * c->fpool_frame_bytes : nullptr;
                     fp.rows_in = p == 1 ? reach : sweep_u;
                     fp.sweep_rows = p == 1 ? sweep_u : nr_c;
                     fp.rows_out = p == 1 ? sweep_u : 0;
                 }
                 const sn::PlaneArgs a = frames_from(pa[p], i);
-                if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), m, &fp));
-                else SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), m, &fp));
+                if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), m, &fp));
+                else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), m, &fp));
             }
         }
         c->fused_frames += n;
@@ -386,16 +421,16 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
     for (int p = 0; p < c->nplanes(); ++p) {
         const sn::PlaneArgs& a = pa[p];
         if (fused[p] && !c->fused420) {
-            if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(c->stream, a, c->threshold(p), n));
-            else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(c->stream, a, c->threshold(p), n, nullptr));
+            if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n));
+            else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, nullptr));
             else if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w))
-                SN_HIP(c, sn::launch_fused_u8_v3(c->stream, a, c->threshold(p), n, nullptr));
-            else SN_HIP(c, sn::launch_fused_u8(c->stream, a, c->threshold(p), n));
+                SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, nullptr));
+            else SN_HIP(c, sn::launch_fused_u8(st, a, c->threshold(p), n));
             if (!counted) c->fused_frames += n;
             counted = true;
             continue;
         }
-        SN_HIP(c, sn::launch_assemble(c->stream, a, c->cfg.bytes_per_sample, n));
+        SN_HIP(c, sn::launch_assemble(st, a, c->cfg.bytes_per_sample, n));
         pool_path = pool_path || a.enabled;
     }
     if (!pool_path) return SN_OK;
@@ -408,8 +443,8 @@ static int run_group(Context* c, int n, const void* const src[3], const int64_t 
         const int m = n - i < c->slots ? n - i : c->slots;
         for (int p = 0; p < c->nplanes(); ++p) {
             if (!pa[p].enabled || (fused[p] && !c->fused420)) continue;
-            SN_HIP(c, sn::launch_pool_plane(c->stream, frames_from(pa[p], i), c->pool, c->cfg.bytes_per_sample,
-                                            c->threshold(p), m, 0));
+            SN_HIP(c, sn::launch_pool_plane(st, frames_from(pa[p], i), c->pool, c->cfg.bytes_per_sample,
+                                            c->threshold(p), m, slot0));
         }
     }
     return SN_OK;
@@ -437,7 +472,7 @@ int sn_process_device_strided(sn_context* h, int32_t nframes, const void* const 
         int g = f + 1;
         if (c->history_free)
             while (g < nframes && field_offset(c, parity ? parity[g] : 1) == off) ++g;
-        rc = run_group(c, g - f, src, sfs, sp, dst, dfs, dp, f, off);
+        rc = run_group(c, c->stream, 0, g - f, src, sfs, sp, dst, dfs, dp, f, off);
         if (rc != SN_OK) return rc;
         f = g;
     }
@@ -486,12 +521,125 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     return SN_OK;
 }
 
+// ---- the host ring: SURVEY 8(f)-1, pipelining behind GetFrame --------------------------------------------
+// Each slot has pinned staging for one source and one output frame, device copies of both and a stream of its
+// own: H2D, the sweeps and D2H of one frame are queued back to back on that stream and overlap with the other
+// slots' work.  History-carrying configurations keep the reference's frame order: a slot's sweeps wait for the
+// previous submission's sweeps (and all of them use scratch slot 0).
+static int ensure_ring(Context* c)
+{
+    if (!c->ring.empty()) return SN_OK;
+    const int B = c->cfg.bytes_per_sample;
+    int depth = c->host_depth;
+    if (c->history_free) {  // every frame in flight needs scratch of its own
+        if (!c->use_fused && depth > c->slots) depth = c->slots;
+        if (c->fused420 && depth > c->fslots) depth = c->fslots;
+    }
+    for (int p = 0; p < c->nplanes(); ++p) {
+        c->ring_pitch_in[p] = (c->plane_w(p) * B + 255) & ~255;
+        c->ring_pitch_out[p] = c->ring_pitch_in[p];
+    }
+    c->ring.resize(depth);
+    for (auto& hs : c->ring) {
+        SN_HIP(c, hipStreamCreateWithFlags(&hs.stream, hipStreamNonBlocking));
+        SN_HIP(c, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+        SN_HIP(c, hipEventCreateWithFlags(&hs.swept, hipEventDisableTiming));
+        for (int p = 0; p < c->nplanes(); ++p) {
+            const size_t nin = (size_t)c->ring_pitch_in[p] * c->plane_h_in(p), nout = (size_t)c->ring_pitch_out[p] * c->plane_h_out(p);
+            SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&hs.pin_in[p]), nin, hipHostMallocDefault));
+            SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&hs.pin_out[p]), nout, hipHostMallocDefault));
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&hs.dev_in[p]), nin));
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&hs.dev_out[p]), nout));
+        }
+    }
+    return SN_OK;
+}
+
+static void copy_rows(uint8_t* dst, int dpitch, const uint8_t* src, int spitch, int row_bytes, int rows)
+{
+    if (dpitch == spitch && dpitch == row_bytes) {
+        memcpy(dst, src, (size_t)row_bytes * rows);
+        return;
+    }
+    for (int y = 0; y < rows; ++y) memcpy(dst + (size_t)y * dpitch, src + (size_t)y * spitch, row_bytes);
+}
+
+int sn_host_slots(sn_context* h)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return 0;
+    if (hipSetDevice(c->device) != hipSuccess || ensure_ring(c) != SN_OK) return 0;
+    return (int)c->ring.size();
+}
+
+int sn_submit_host(sn_context* h, const void* const src[3], const int32_t sp[3], int32_t parity, int32_t* slot_out)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (!src || !sp || !slot_out) return sn::fail(c, SN_ERR_INVALID_ARG, "plane array / slot pointer is NULL");
+    const int B = c->cfg.bytes_per_sample;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        if (!src[p]) return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pointer is NULL", p);
+        if (sp[p] < c->plane_w(p) * B) return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pitch smaller than the row size %d", p, c->plane_w(p) * B);
+    }
+    SN_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_ring(c);
+    if (rc != SN_OK) return rc;
+    const int slot = c->ring_next;
+    Context::HostSlot& hs = c->ring[slot];
+    if (hs.busy) return sn::fail(c, SN_ERR_BUSY, "all %d host slots are in flight: collect slot %d first", (int)c->ring.size(), slot);
+
+    const void* dsrc[3] = {hs.dev_in[0], hs.dev_in[1], hs.dev_in[2]};
+    void* ddst[3] = {hs.dev_out[0], hs.dev_out[1], hs.dev_out[2]};
+    for (int p = 0; p < c->nplanes(); ++p) {
+        copy_rows(hs.pin_in[p], c->ring_pitch_in[p], static_cast<const uint8_t*>(src[p]), sp[p], c->plane_w(p) * B, c->plane_h_in(p));
+        SN_HIP(c, hipMemcpyAsync(hs.dev_in[p], hs.pin_in[p], (size_t)c->ring_pitch_in[p] * c->plane_h_in(p), hipMemcpyHostToDevice, hs.stream));
+    }
+    if (!c->history_free && c->ring_last >= 0) SN_HIP(c, hipStreamWaitEvent(hs.stream, c->ring[c->ring_last].swept, 0));
+    const int64_t zero[3] = {0, 0, 0};
+    rc = run_group(c, hs.stream, c->history_free ? slot : 0, 1, dsrc, zero, c->ring_pitch_in, ddst, zero, c->ring_pitch_out, 0,
+                   field_offset(c, parity));
+    if (rc != SN_OK) return rc;
+    SN_HIP(c, hipEventRecord(hs.swept, hs.stream));
+    for (int p = 0; p < c->nplanes(); ++p)
+        SN_HIP(c, hipMemcpyAsync(hs.pin_out[p], hs.dev_out[p], (size_t)c->ring_pitch_out[p] * c->plane_h_out(p), hipMemcpyDeviceToHost, hs.stream));
+    SN_HIP(c, hipEventRecord(hs.done, hs.stream));
+    hs.busy = true;
+    c->ring_last = slot;
+    c->ring_next = (slot + 1) % (int)c->ring.size();
+    c->frames += 1;
+    *slot_out = slot;
+    return SN_OK;
+}
+
+int sn_collect_host(sn_context* h, int32_t slot, void* const dst[3], const int32_t dp[3])
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (slot < 0 || slot >= (int)c->ring.size() || !c->ring[slot].busy) return sn::fail(c, SN_ERR_INVALID_ARG, "slot %d holds no frame", slot);
+    if (!dst || !dp) return sn::fail(c, SN_ERR_INVALID_ARG, "plane array is NULL");
+    const int B = c->cfg.bytes_per_sample;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        if (!dst[p]) return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pointer is NULL", p);
+        if (dp[p] < c->plane_w(p) * B) return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pitch smaller than the row size %d", p, c->plane_w(p) * B);
+    }
+    SN_HIP(c, hipSetDevice(c->device));
+    Context::HostSlot& hs = c->ring[slot];
+    SN_HIP(c, hipEventSynchronize(hs.done));
+    for (int p = 0; p < c->nplanes(); ++p)
+        copy_rows(static_cast<uint8_t*>(dst[p]), dp[p], hs.pin_out[p], c->ring_pitch_out[p], c->plane_w(p) * B, c->plane_h_out(p));
+    hs.busy = false;
+    return SN_OK;
+}
+
 int sn_synchronize(sn_context* h)
 {
     Context* c = reinterpret_cast<Context*>(h);
     if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
     SN_HIP(c, hipSetDevice(c->device));
     SN_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& hs : c->ring)
+        if (hs.stream) SN_HIP(c, hipStreamSynchronize(hs.stream));
     return SN_OK;
 }
 

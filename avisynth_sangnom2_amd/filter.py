@@ -63,7 +63,8 @@ class SangNom2:
 
     def __init__(self, clip: ClipFormat, order: int = 1, aa: int = 48, aac: int = 0, threads: int = 0,
                  dh: bool = False, luma: bool = True, chroma: bool = True, opt: int = -1,
-                 device: int = 0, max_batch: int = 1, mode: str = "auto", stream: int | None = None):
+                 device: int = 0, max_batch: int = 1, mode: str = "auto", stream: int | None = None,
+                 host_depth: int = 0):
         # `threads` is a dummy in the reference (README.md:40-41); `opt` picks its CPU code path.
         if opt < -1 or opt > 1:
             raise SangNomError(capi.SN_ERR_CONFIG, "SangNom2: opt must be between -1..2.")  # sic, SangNom2.cpp:420
@@ -73,7 +74,7 @@ class SangNom2:
             struct_size=ctypes.sizeof(capi.SnConfig), width=clip.width, height=clip.height,
             bytes_per_sample=clip.bytes, bits_per_sample=clip.bits, num_planes=clip.planes,
             sub_w=clip.subw, sub_h=clip.subh, order=order, aa=aa, aac=aac, dh=int(dh), luma=int(luma),
-            chroma=int(chroma), device=device, max_batch=max_batch, mode=capi.MODES[mode], reserved=0,
+            chroma=int(chroma), device=device, max_batch=max_batch, mode=capi.MODES[mode], host_depth=host_depth,
             stream=stream)
         self._cfg = cfg
         self.max_batch = max_batch
@@ -161,6 +162,34 @@ class SangNom2:
                 raise ValueError("planes must be contiguous along x")
             sp[p], dp[p], spi[p], dpi[p] = s.ctypes.data, d.ctypes.data, s.strides[0], d.strides[0]
         self._check(self._lib.sn_process_host(self._h, sp, spi, dp, dpi, int(parity)))
+        return dst
+
+    # -- GetFrame with look-ahead: the host ring ------------------------------------------------------
+    def host_slots(self) -> int:
+        return self._lib.sn_host_slots(self._h)
+
+    def _plane_args(self, planes, shape_of):
+        ptr, pitch = (ctypes.c_void_p * 3)(), (ctypes.c_int32 * 3)()
+        for p in range(self.nplanes):
+            a = planes[p]
+            if a.dtype != self.clip.dtype or a.shape != shape_of(p) or a.strides[1] != self.clip.bytes:
+                raise ValueError(f"plane {p}: expected {shape_of(p)} {self.clip.dtype}, x-contiguous")
+            ptr[p], pitch[p] = a.ctypes.data, a.strides[0]
+        return ptr, pitch
+
+    def submit(self, src, parity: int = 1) -> int:
+        """Queue one host frame (H2D, sweeps, D2H on a ring slot's own stream); returns the slot."""
+        sp, spi = self._plane_args(src, self.plane_shape_in)
+        slot = ctypes.c_int32(-1)
+        self._check(self._lib.sn_submit_host(self._h, sp, spi, int(parity), ctypes.byref(slot)))
+        return slot.value
+
+    def collect(self, slot: int, dst=None):
+        """Wait for the frame in `slot` and copy it into host planes."""
+        if dst is None:
+            dst = [np.zeros(self.plane_shape_out(p), dtype=self.clip.dtype) for p in range(self.nplanes)]
+        dp, dpi = self._plane_args(dst, self.plane_shape_out)
+        self._check(self._lib.sn_collect_host(self._h, int(slot), dp, dpi))
         return dst
 
     def get_frame_device(self, src, dst, parity: int = 1):

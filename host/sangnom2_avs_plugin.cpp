@@ -33,6 +33,7 @@ struct AvsHost {
     static int NumComponents(const Info& v) { return v.NumComponents(); }
     static int SubW(const Info& v) { return v.GetPlaneWidthSubsampling(PLANAR_U); }
     static int SubH(const Info& v) { return v.GetPlaneHeightSubsampling(PLANAR_U); }
+    static int NumFrames(const Info& v) { return v.num_frames; }
     static bool IsRGB(const Info& v) { return v.IsRGB(); }
     static bool IsPlanar(const Info& v) { return v.IsPlanar(); }
     static bool Is420(const Info& v) { return v.Is420(); }

@@ -7,11 +7,17 @@
 // GetFrame hands the source planes to sn_process_host and receives the assembled output frame
 // (kept field, border line, interpolated lines) in the destination planes.
 //
+// With Args::lookahead > 1 GetFrame(n) keeps frames n .. n+lookahead-1 in flight on the library's host ring
+// (sn_submit_host / sn_collect_host): it requests the child's next frames ahead of the
+// caller, so their transfers and sweeps overlap; a request out of sequence drains the ring and restarts there.
+//
 // The class is a template over a host-traits type so that the same code serves the real AviSynth+
 // SDK (host/sangnom2_avs_plugin.cpp) and this repository's test host (host/sn_host_api.h).
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
+#include <deque>
 #include <string>
 
 #include "sangnom_hip.h"
@@ -28,6 +34,7 @@ struct Args {  // SangNom2(clip, order, aa, aac, threads, dh, luma, chroma, opt)
     bool chroma = true;
     int opt = -1;     // the reference's CPU code-path switch; validated, otherwise unused
     int device = 0;   // HIP device ordinal (not a script argument)
+    int lookahead = -1;  // frames in flight behind GetFrame; -1: $SANGNOM_LOOKAHEAD or 1 (synchronous)
 };
 
 template <class Host>
@@ -70,20 +77,38 @@ public:
         c.device = a.device;
         c.max_batch = 1;
         c.mode = SN_MODE_AUTO;
+        int la = a.lookahead;
+        if (la < 0) {
+            const char* e = std::getenv("SANGNOM_LOOKAHEAD");
+            la = e ? std::atoi(e) : 1;
+        }
+        c.host_depth = std::max(1, std::min(la, 256));
         const int rc = sn_create(&c, &ctx_);
         if (rc != SN_OK) env->ThrowError("%s: %s", name, sn_last_error(nullptr));
         if (a.dh) Host::SetHeight(vi_, Host::Height(vi_) * 2);  // src/SangNom2.cpp:284-285
         planes_ = c.num_planes;
+        num_frames_ = Host::NumFrames(vi_);
+        // look-ahead processes frames the caller may never ask for; where results depend on the order of
+        // processing (history-carrying configurations) GetFrame therefore stays synchronous
+        sn_info info{};
+        info.struct_size = (int32_t)sizeof info;
+        const bool ahead = c.host_depth > 1 && sn_get_info(ctx_, &info) == SN_OK && info.history_free;
+        slots_ = ahead ? sn_host_slots(ctx_) : 1;
     }
     Filter(const Filter&) = delete;
     Filter& operator=(const Filter&) = delete;
-    ~Filter() { sn_destroy(ctx_); }
+    ~Filter()
+    {
+        inflight_.clear();  // frames still in the ring are dropped with the context
+        sn_destroy(ctx_);
+    }
 
     const Info& GetInfo() const { return vi_; }
 
     // SangNom2::GetFrame, src/SangNom2.cpp:332-397.
     FramePtr GetFrame(int n, Env* env)
     {
+        if (slots_ > 1) return GetFrameAhead(n, env);
         FramePtr src = Host::GetFrame(child_, n, env);
         FramePtr dst = Host::NewFrame(env, vi_, src);
         const void* sp[3] = {nullptr, nullptr, nullptr};
@@ -106,6 +131,60 @@ public:
     static constexpr bool kMultiInstance = true;
 
 private:
+    struct Pending {
+        int n;
+        FramePtr src, dst;  // src is held until its planes have been staged (submit copies them at once)
+        int32_t slot;
+    };
+
+    void Planes(const FramePtr& src, const FramePtr& dst, const void* sp[3], int32_t spitch[3], void* dp[3], int32_t dpitch[3])
+    {
+        for (int p = 0; p < planes_; ++p) {
+            if (src) { sp[p] = Host::ReadPtr(src, p); spitch[p] = Host::Pitch(src, p); }
+            if (dst) { dp[p] = Host::WritePtr(dst, p); dpitch[p] = Host::Pitch(dst, p); }
+        }
+    }
+
+    FramePtr Collect(Env* env)
+    {
+        Pending p = inflight_.front();
+        inflight_.pop_front();
+        const void* sp[3] = {nullptr, nullptr, nullptr};
+        void* dp[3] = {nullptr, nullptr, nullptr};
+        int32_t spitch[3] = {0, 0, 0}, dpitch[3] = {0, 0, 0};
+        Planes(FramePtr(), p.dst, sp, spitch, dp, dpitch);
+        if (sn_collect_host(ctx_, p.slot, dp, dpitch) != SN_OK) env->ThrowError("SangNom2: %s", sn_last_error(ctx_));
+        return p.dst;
+    }
+
+    FramePtr GetFrameAhead(int n, Env* env)
+    {
+        if (inflight_.empty() || inflight_.front().n != n) {  // not the frame at the head: start over at n
+            while (!inflight_.empty()) Collect(env);
+            next_ = n;
+        }
+        while ((int)inflight_.size() < slots_ && next_ < num_frames_) {
+            Pending p;
+            p.n = next_++;
+            p.src = Host::GetFrame(child_, p.n, env);
+            p.dst = Host::NewFrame(env, vi_, p.src);
+            const void* sp[3] = {nullptr, nullptr, nullptr};
+            void* dp[3] = {nullptr, nullptr, nullptr};
+            int32_t spitch[3] = {0, 0, 0}, dpitch[3] = {0, 0, 0};
+            Planes(p.src, FramePtr(), sp, spitch, dp, dpitch);
+            const int parity = args_.order == 0 ? (Host::GetParity(child_, p.n) ? 1 : 0) : 1;
+            if (sn_submit_host(ctx_, sp, spitch, parity, &p.slot) != SN_OK) env->ThrowError("SangNom2: %s", sn_last_error(ctx_));
+            p.src = FramePtr();
+            inflight_.push_back(p);
+        }
+        if (inflight_.empty()) env->ThrowError("SangNom2: frame %d is outside the clip", n);
+        return Collect(env);
+    }
+
+    std::deque<Pending> inflight_;
+    int next_ = 0;
+    int num_frames_ = 0;
+    int slots_ = 1;
     ClipPtr child_;
     Args args_;
     Info vi_{};

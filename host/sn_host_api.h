@@ -28,6 +28,7 @@ struct ClipInfo {  // the VideoInfo fields the filter reads (SangNom2.cpp:281-28
     int bits_per_component = 8;
     int num_components = 1;    // 1 = Y, 3 = YUV
     int sub_w = 0, sub_h = 0;  // log2 chroma subsampling
+    int num_frames = 0;
     bool rgb = false, planar = true;
     bool Is420() const { return num_components >= 3 && sub_w == 1 && sub_h == 1; }
     int PlaneWidth(int p) const { return p == 0 ? width : width >> sub_w; }
@@ -96,6 +97,7 @@ struct TestHost {
     static int NumComponents(const Info& v) { return v.num_components; }
     static int SubW(const Info& v) { return v.sub_w; }
     static int SubH(const Info& v) { return v.sub_h; }
+    static int NumFrames(const Info& v) { return v.num_frames; }
     static bool IsRGB(const Info& v) { return v.rgb; }
     static bool IsPlanar(const Info& v) { return v.planar; }
     static bool Is420(const Info& v) { return v.Is420(); }

@@ -2,12 +2,15 @@
 // engine drives the reference plugin: build a source clip, construct SangNom2(clip, ...), request
 // frames with GetFrame(n).  tests/test_host_adapter.py feeds it frames and compares the output with
 // the oracle.
-//   sn_host_test <in.bin> <out.bin>
+//   sn_host_test <in.bin> <out.bin> [lookahead [first-frame-order...]]
+// lookahead > 1 runs GetFrame over the host ring; the optional list gives the order in which frames are
+// requested (default 0 .. nframes-1), e.g. to exercise a seek.
 // in.bin : 14 x int32 {w,h,bytes,bits,planes,subw,subh,order,aa,aac,dh,luma,chroma,nframes}, then per
 //          frame: int32 parity + the planes, tightly packed.
 // out.bin: per frame the output planes, tightly packed.  On a constructor error: exit code 3 and
 //          the message on stdout.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,7 +40,7 @@ public:
 
 int main(int argc, char** argv)
 {
-    if (argc != 3) return 2;
+    if (argc < 3) return 2;
     FILE* in = fopen(argv[1], "rb");
     if (!in) return 2;
     int32_t h[14];
@@ -58,6 +61,12 @@ int main(int argc, char** argv)
     a.luma = h[11] != 0;
     a.chroma = h[12] != 0;
     const int nframes = h[13];
+    clip->vi.num_frames = nframes;
+    if (argc > 3) a.lookahead = atoi(argv[3]);
+    std::vector<int> order;
+    for (int i = 4; i < argc; ++i) order.push_back(atoi(argv[i]));
+    if (order.empty())
+        for (int n = 0; n < nframes; ++n) order.push_back(n);
     size_t frame_bytes = 0;
     for (int p = 0; p < clip->vi.num_components; ++p)
         frame_bytes += (size_t)clip->vi.PlaneWidth(p) * clip->vi.component_size * clip->vi.PlaneHeight(p);
@@ -76,7 +85,7 @@ int main(int argc, char** argv)
         sangnom::Filter<TestHost> flt(clip, a, &env);
         FILE* out = fopen(argv[2], "wb");
         if (!out) return 2;
-        for (int n = 0; n < nframes; ++n) {
+        for (int n : order) {
             FramePtr d = flt.GetFrame(n, &env);
             for (int p = 0; p < clip->vi.num_components; ++p)
                 for (int y = 0; y < d->Height(p); ++y)

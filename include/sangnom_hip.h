@@ -44,7 +44,8 @@ enum {
     SN_ERR_CONFIG = 2,      /* rejected by the reference's own checks; message = its text     */
     SN_ERR_HIP = 3,         /* a HIP runtime call failed; message names it                    */
     SN_ERR_NO_DEVICE = 4,   /* no usable HIP device                                           */
-    SN_ERR_UNSUPPORTED = 5  /* geometry outside what the kernels handle (see sn_create)       */
+    SN_ERR_UNSUPPORTED = 5, /* geometry outside what the kernels handle (see sn_create)       */
+    SN_ERR_BUSY = 6         /* sn_submit_host: every slot of the host ring holds a frame      */
 };
 
 /* Execution path selection (sn_config.mode). */
@@ -75,7 +76,7 @@ typedef struct sn_config {
     int32_t device;           /* HIP device ordinal                                          */
     int32_t max_batch;        /* frames one sn_process_device_strided call may carry (>= 1)  */
     int32_t mode;             /* SN_MODE_*                                                   */
-    int32_t reserved;
+    int32_t host_depth;       /* frames sn_submit_host may keep in flight (0 = 4)            */
     void*   stream;           /* hipStream_t to run on; NULL = the context creates its own   */
 } sn_config;
 
@@ -127,6 +128,19 @@ int sn_process_device_strided(sn_context* ctx, int32_t nframes,
                               const int32_t src_pitch[3],
                               void* const dst[3], const int64_t dst_frame_stride[3],
                               const int32_t dst_pitch[3], const int32_t* parity);
+
+/* Pipelined host path (what a plugin's GetFrame with look-ahead binds).  The context owns
+ * sn_host_slots() frame slots (cfg.host_depth, fewer if scratch is short), each with pinned staging, device
+ * buffers and a stream of its own.  sn_submit_host copies the source planes into the next slot and queues H2D,
+ * the kernels and D2H without waiting; sn_collect_host waits for that slot and copies the output planes out.
+ * Transfers and sweeps of different slots overlap.  Slots are handed out round-robin, so collecting in
+ * submission order never blocks on a later frame; SN_ERR_BUSY means the next slot has not been collected.
+ * History-carrying configurations (sn_info.history_free == 0) still sweep their frames in submission order.
+ * Not thread-safe per context; do not interleave with the batch entry points without sn_synchronize. */
+int sn_host_slots(sn_context* ctx);
+int sn_submit_host(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3], int32_t parity,
+                   int32_t* slot);
+int sn_collect_host(sn_context* ctx, int32_t slot, void* const dst[3], const int32_t dst_pitch[3]);
 
 int sn_synchronize(sn_context* ctx);
 void* sn_get_stream(sn_context* ctx); /* the hipStream_t the context launches on */

@@ -5,6 +5,8 @@ luma, chroma), request frames, compare with opt=0 semantics
 (/root/reference/src/SangNom2.cpp:259-273, :332-397).  Float planes are compared on their bit
 patterns (north_star allows 1 ulp; we hold 0).
 """
+from contextlib import nullcontext as _nullcontext
+
 import numpy as np
 import pytest
 
@@ -397,3 +399,37 @@ def test_batch_larger_than_the_scratch_budget_runs_in_chunks(hip_lib, monkeypatc
         for p in range(clip.planes):
             got = dst[p][f].cpu().numpy().view(clip.dtype)
             assert same(want[p], got), f"frame {f} plane {p}: " + describe_diff(want[p], got)
+
+
+@pytest.mark.parametrize("fmt,w,h,kw,depth", [
+    ("Y8", 1920, 64, {}, 4),
+    ("YUV420P8", 256, 64, dict(aac=48), 3),            # fused 4:2:0: one pair of hand-off pools per slot
+    ("YUV420P16", 256, 64, dict(aac=48, order=0), 5),
+    ("YUV444PS", 128, 48, dict(aac=48, dh=True), 2),
+    ("Y8", 100, 40, {}, 4),                            # width % 32 != 0: pool state carries, frames stay in order
+    ("YUV420P8", 72, 32, dict(aac=48, order=0), 3),    # history-carrying, parity alternates
+])
+def test_host_ring_pipelines_frames_like_get_frame(hip_lib, fmt, w, h, kw, depth):
+    """sn_submit_host / sn_collect_host with several frames in flight == one oracle instance fed in order."""
+    clip = clip_format(fmt, w, h)
+    N = 11
+    frames = make_frames(clip, "noise", N, seed0=41)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    want = [ora.process(frames[f], parity=f & 1) for f in range(N)]
+    with SangNom2(clip, host_depth=depth, **kw) as flt:
+        slots = flt.host_slots()
+        assert 1 <= slots <= depth
+        inflight, got = [], []
+        for f in range(N):
+            if len(inflight) == slots:
+                got.append(flt.collect(inflight.pop(0)))
+            inflight.append(flt.submit(frames[f], parity=f & 1))
+        with pytest.raises(SangNomError, match="in flight") if len(inflight) == slots else _nullcontext():
+            flt.submit(frames[0])
+        while inflight:
+            got.append(flt.collect(inflight.pop(0)))
+        with pytest.raises(SangNomError, match="holds no frame"):
+            flt.collect(0)
+    for f in range(N):
+        for p in range(len(want[f])):
+            assert same(want[f][p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])

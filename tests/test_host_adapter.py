@@ -21,7 +21,7 @@ def _build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "sn_host_test"])
 
 
-def _run(tmp_path, clip, kw, frames, parities):
+def _run(tmp_path, clip, kw, frames, parities, extra=()):
     _build()
     hdr = [clip.width, clip.height, clip.bytes, clip.bits, clip.planes, clip.subw, clip.subh,
            kw.get("order", 1), kw.get("aa", 48), kw.get("aac", 0), int(kw.get("dh", False)),
@@ -33,7 +33,7 @@ def _run(tmp_path, clip, kw, frames, parities):
             f.write(struct.pack("<i", par))
             for pl in fr:
                 f.write(np.ascontiguousarray(pl).tobytes())
-    r = subprocess.run([BIN, fin, fout], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([BIN, fin, fout, *[str(x) for x in extra]], capture_output=True, text=True, timeout=300)
     return r, fout
 
 
@@ -73,4 +73,33 @@ def test_getframe_matches_oracle(tmp_path, fmt, w, h, kw):
             got = raw[pos:pos + wpl.nbytes].view(wpl.dtype).reshape(wpl.shape)
             pos += wpl.nbytes
             assert same(wpl, got), f"{fmt} frame {f} plane {p}"
+    assert pos == raw.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,w,h,kw", [
+    ("Y8", 256, 64, dict(order=0, aa=48)),
+    ("YUV420P8", 128, 64, dict(aac=48)),
+    ("Y8", 100, 40, dict(aa=20)),              # history-carrying: GetFrame stays synchronous
+])
+def test_getframe_with_lookahead_and_a_seek(tmp_path, fmt, w, h, kw):
+    """Args::lookahead = 4: frames are requested ahead of the caller over the host ring; the request order
+    0 1 2 6 7 8 3 4 (two seeks) must give the frames a synchronous filter gives (history-free clips: every
+    frame on its own; the history-carrying clip is checked against one oracle fed in request order)."""
+    clip = clip_format(fmt, w, h)
+    N = 9
+    frames = [synth.frame(clip, "noise", seed=70 + i) for i in range(N)]
+    parities = [i & 1 for i in range(N)]
+    order = [0, 1, 2, 6, 7, 8, 3, 4]
+    r, fout = _run(tmp_path, clip, kw, frames, parities, extra=[4] + order)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    raw = np.fromfile(fout, dtype=np.uint8)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    pos = 0
+    for n in order:
+        want = ora.process(frames[n], parity=parities[n])
+        for p, wpl in enumerate(want):
+            got = raw[pos:pos + wpl.nbytes].view(wpl.dtype).reshape(wpl.shape)
+            pos += wpl.nbytes
+            assert same(wpl, got), f"{fmt} request {n} plane {p}"
     assert pos == raw.size
