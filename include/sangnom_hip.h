@@ -130,12 +130,14 @@ int sn_process_device_strided(sn_context* ctx, int32_t nframes,
                               const int32_t dst_pitch[3], const int32_t* parity);
 
 /* Pipelined host path (what a plugin's GetFrame with look-ahead binds).  The context owns
- * sn_host_slots() frame slots (cfg.host_depth, fewer if scratch is short), each with pinned staging, device
- * buffers and a stream of its own.  sn_submit_host copies the source planes into the next slot and queues H2D,
- * the kernels and D2H without waiting; sn_collect_host waits for that slot and copies the output planes out.
- * Transfers and sweeps of different slots overlap.  Slots are handed out round-robin, so collecting in
- * submission order never blocks on a later frame; SN_ERR_BUSY means the next slot has not been collected.
- * History-carrying configurations (sn_info.history_free == 0) still sweep their frames in submission order.
+ * sn_host_slots() frame slots (about cfg.host_depth; fewer if scratch is short), each with pinned staging and
+ * device buffers for one source and one output frame.  sn_submit_host copies the source planes into the next
+ * slot and queues its H2D without waiting; the slots form up to four groups, and when a group is full (or one
+ * of its frames is collected early) one launch sweeps its frames on the group's stream, D2H behind it.
+ * sn_collect_host waits for the slot's group and copies the output planes out.  Transfers and sweeps of
+ * different groups overlap.  Slots are handed out round-robin, so collecting in submission order never blocks
+ * on a later frame; SN_ERR_BUSY means the next slot has not been collected.  History-carrying configurations
+ * (sn_info.history_free == 0) still sweep their frames in submission order.
  * Not thread-safe per context; do not interleave with the batch entry points without sn_synchronize. */
 int sn_host_slots(sn_context* ctx);
 int sn_submit_host(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3], int32_t parity,
