@@ -82,3 +82,13 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "sangnom_oracle", "oracle/"):
                     assert needle not in text, f"{f} refers to the oracle ({needle!r})"
+
+
+def test_staging_copy_pool_is_race_free_under_tsan():
+    """sn::Copier (the host ring's staging copies on worker threads) under ThreadSanitizer, every byte checked."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "host"), "copier_test"])
+    for workers in (0, 3, 7):
+        r = subprocess.run([os.path.join(root, "host", "copier_test"), str(workers), "40"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-500:], r.stderr[-2000:])
