@@ -33,6 +33,11 @@ struct Context {
     bool use_fused = false;
 
     PoolArgs pool{};  // allocated on first use when the fused kernels serve the configuration
+
+    // cfg.isolated_planes: every plane is its own filter instance (own pool geometry, own pool)
+    bool isolated = false;
+    PoolArgs plane_pool[3] = {};
+    bool plane_fused[3] = {false, false, false};
     int slots = 1;    // frames of a batch the pool path runs at once (1: frames in order on slot 0)
 
     int fslots = 1;   // frames per chunk of the fused 4:2:0 sweeps (each needs its two hand-off pools)
@@ -140,6 +145,7 @@ static const char* structural_text(const sn_config& c)
         return "luma size must be a multiple of the chroma subsampling";
     if (c.max_batch < 0) return "max_batch must be >= 0";
     if (c.host_depth < 0 || c.host_depth > 256) return "host_depth must be 0..256";
+    if (c.isolated_planes != 0 && c.isolated_planes != 1) return "isolated_planes must be 0 or 1";
     if (c.mode < SN_MODE_AUTO || c.mode > SN_MODE_FUSED) return "mode must be SN_MODE_AUTO/POOL/FUSED";
     return nullptr;
 }
@@ -193,6 +199,8 @@ void sn_destroy(sn_context* h)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->pool.base) (void)hipFree(c->pool.base);
+    for (int p = 0; p < 3; ++p)
+        if (c->plane_pool[p].base) (void)hipFree(c->plane_pool[p].base);
     for (int i = 0; i < 2; ++i)
         if (c->fpool[i]) (void)hipFree(c->fpool[i]);
     for (auto& g : c->ring)
@@ -226,11 +234,12 @@ static int64_t scratch_budget()
 }
 
 // The pool: zero-filled (the convention that makes the reference's output defined).
-static int ensure_pool(Context* c)
+static int ensure_pool(Context* c, int plane = 0)
 {
-    if (c->pool.base) return SN_OK;
-    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->pool.base), (size_t)c->pool.slot_bytes * c->slots));
-    SN_HIP(c, hipMemsetAsync(c->pool.base, 0, (size_t)c->pool.slot_bytes * c->slots, c->stream));
+    sn::PoolArgs& pool = c->isolated ? c->plane_pool[plane] : c->pool;
+    if (pool.base) return SN_OK;
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&pool.base), (size_t)pool.slot_bytes * c->slots));
+    SN_HIP(c, hipMemsetAsync(pool.base, 0, (size_t)pool.slot_bytes * c->slots, c->stream));
     SN_HIP(c, hipStreamSynchronize(c->stream));  // the first user may be a ring slot's stream
     return SN_OK;
 }
@@ -264,13 +273,33 @@ static int create_impl(const sn_config* cfg, Context* c)
     if (c->out_height / 2 > 65535)
         return sn::fail(c, SN_ERR_UNSUPPORTED, "height %d exceeds the supported maximum", cfg->height);
     c->history_free = sn::compute_history_free(*c);
+    c->isolated = cfg->isolated_planes != 0 && c->nplanes() > 1;
 
-    const bool eligible = sn::fused_eligible(c->cfg);
+    bool eligible = sn::fused_eligible(c->cfg);
+    if (c->isolated) {
+        // Every plane as its own Y clip: pool stride and height from the plane itself, nothing shared -- what a
+        // script gets from ExtractY/U/V -> SangNom2 -> CombinePlanes with the reference.  A plane is history-free
+        // iff its own width is a multiple of 32, and then the plain fused sweep serves it.
+        c->history_free = true;
+        eligible = true;
+        for (int p = 0; p < c->nplanes(); ++p) {
+            sn::PoolArgs& pool = c->plane_pool[p];
+            pool.stride_e = (c->plane_w(p) + 31) & ~31;
+            pool.bh = (c->plane_h_out(p) + 1) >> 1;
+            pool.slot_bytes = ((int64_t)sn::kBuffers * (pool.bh + 1) * pool.stride_e * cfg->bytes_per_sample + 255) & ~(int64_t)255;
+            if (!(cfg->dh || c->process[p])) continue;  // copied planes need nothing
+            if (pool.stride_e != c->plane_w(p)) c->history_free = false;
+            c->plane_fused[p] = sn::fused_plane_eligible(cfg->bytes_per_sample, c->plane_w(p));
+            eligible = eligible && c->plane_fused[p];
+        }
+    }
     if (cfg->mode == SN_MODE_FUSED && !eligible)
         return sn::fail(c, SN_ERR_UNSUPPORTED, "SN_MODE_FUSED requested but this configuration is not eligible");
     c->use_fused = eligible && cfg->mode != SN_MODE_POOL;
 
-    c->fused420 = c->use_fused && sn::fused_needs_pools(c->cfg);
+    c->fused420 = c->use_fused && !c->isolated && sn::fused_needs_pools(c->cfg);
+    if (c->isolated && cfg->mode == SN_MODE_POOL)
+        for (int p = 0; p < 3; ++p) c->plane_fused[p] = false;
     if (cfg->stream) {
         c->stream = reinterpret_cast<hipStream_t>(cfg->stream);
     } else {
@@ -292,8 +321,11 @@ static int create_impl(const sn_config* cfg, Context* c)
     };
     c->slots = c->history_free ? fit(c->pool.slot_bytes) : 1;
     if (!c->use_fused) {
-        rc = ensure_pool(c);
-        if (rc != SN_OK) return rc;
+        for (int p = 0; p < (c->isolated ? c->nplanes() : 1); ++p) {
+            if (c->isolated && (c->plane_fused[p] || !(cfg->dh || c->process[p]))) continue;
+            rc = ensure_pool(c, p);
+            if (rc != SN_OK) return rc;
+        }
     }
     if (c->fused420) {
         // rows the chroma sweeps can reach: 1 .. min(nr_c + 2, bh - 1), plus row 0
@@ -393,6 +425,35 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     // SN_FUSED_VER=2 selects the previous formulation (sn_fused_u8.hip) for A/B runs
     static const int ver = [] { const char* e = getenv("SN_FUSED_VER"); return e ? atoi(e) : 3; }();
 
+    auto launch_plain_fused = [&](const sn::PlaneArgs& a, int p, int m) -> hipError_t {
+        if (c->cfg.bytes_per_sample == 4) return sn::launch_fused_f32_v3(st, a, c->threshold(p), m);
+        if (c->cfg.bytes_per_sample == 2) return sn::launch_fused_u16_v3(st, a, c->threshold(p), m, nullptr);
+        if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w)) return sn::launch_fused_u8_v3(st, a, c->threshold(p), m, nullptr);
+        return sn::launch_fused_u8(st, a, c->threshold(p), m);
+    };
+
+    if (c->isolated) {  // every plane on its own: plain fused sweep or the pool path over the plane's own pool
+        bool counted = false;
+        for (int p = 0; p < c->nplanes(); ++p) {
+            const sn::PlaneArgs& a = pa[p];
+            if (a.enabled && c->plane_fused[p] && sn::fused_layout_ok(a)) {
+                SN_HIP(c, launch_plain_fused(a, p, n));
+                if (!counted) c->fused_frames += n;
+                counted = true;
+                continue;
+            }
+            SN_HIP(c, sn::launch_assemble(st, a, c->cfg.bytes_per_sample, n));
+            if (!a.enabled) continue;
+            const int rc = ensure_pool(c, p);
+            if (rc != SN_OK) return rc;
+            for (int i = 0; i < n; i += c->slots) {
+                const int m = n - i < c->slots ? n - i : c->slots;
+                SN_HIP(c, sn::launch_pool_plane(st, frames_from(a, i), c->plane_pool[p], c->cfg.bytes_per_sample, c->threshold(p), m, slot0));
+            }
+        }
+        return SN_OK;
+    }
+
     // Fused 4:2:0: the luma sweep leaves its smoothed rows in hand-off pool 0, U reads pool 0 and leaves pool 1,
     // V reads pool 1 -- so the three sweeps of a chunk of frames run back to back on that chunk's pools.
     const bool coupled = c->fused420 && fused[0] && fused[1] && fused[2];
@@ -432,11 +493,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     for (int p = 0; p < c->nplanes(); ++p) {
         const sn::PlaneArgs& a = pa[p];
         if (fused[p] && !c->fused420) {
-            if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n));
-            else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, nullptr));
-            else if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w))
-                SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, nullptr));
-            else SN_HIP(c, sn::launch_fused_u8(st, a, c->threshold(p), n));
+            SN_HIP(c, launch_plain_fused(a, p, n));
             if (!counted) c->fused_frames += n;
             counted = true;
             continue;
@@ -715,6 +772,11 @@ int sn_get_info(sn_context* h, sn_info* info)
     info->pool_stride = c->stride_e;
     info->pool_rows = c->bh + 1;
     info->fused_eligible = sn::fused_eligible(c->cfg) ? 1 : 0;
+    if (c->isolated) {
+        info->fused_eligible = 1;
+        for (int p = 0; p < c->nplanes(); ++p)
+            if ((c->cfg.dh || c->process[p]) && !sn::fused_plane_eligible(c->cfg.bytes_per_sample, c->plane_w(p))) info->fused_eligible = 0;
+    }
     info->history_free = c->history_free ? 1 : 0;
     info->frames = c->frames;
     info->fused_frames = c->fused_frames;

@@ -531,6 +531,13 @@ static bool chroma_subsampled_and_processed(const sn_config& c)
 
 bool fused_needs_pools(const sn_config& c) { return chroma_subsampled_and_processed(c); }
 
+bool fused_plane_eligible(int bytes_per_sample, int w)
+{
+    if (bytes_per_sample == 1) return fused_v3_plane_ok(w) || fused_v2_plane_ok(w);
+    if (bytes_per_sample == 2) return fused_u16_plane_ok(w);
+    return fused_f32_plane_ok(w);
+}
+
 bool fused_eligible(const sn_config& c)
 {
     if (c.bytes_per_sample == 2) {

@@ -45,6 +45,8 @@ hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& 
 // sn_fused_u8.hip: the fused one-pass kernel (8-bit).  launch_fused_u8 also does
 // the plane's frame assembly, so launch_assemble must not be called for a plane it serves.
 bool fused_eligible(const sn_config& c);
+// one plane of width w on its own (plain sweep): sample size and width within what the fused kernels take
+bool fused_plane_eligible(int bytes_per_sample, int w);
 bool fused_needs_pools(const sn_config& c);  // subsampled chroma: luma / chroma sweeps coupled through scratch pools
 bool fused_v2_plane_ok(int w);
 bool fused_layout_ok(const PlaneArgs& p);

@@ -29,6 +29,7 @@ WORKLOADS = {
     "1080p-Y8": ("Y8", 1920, 1080, dict(order=1, aa=48)),
     "4320p-Y8": ("Y8", 7680, 4320, dict(order=1, aa=48)),
     "2160p-YUV420P8": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "2160p-YUV420P8-isolated": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48, isolated_planes=True)),
     "2160p-Y16": ("Y16", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420P16": ("YUV420P16", 3840, 2160, dict(order=1, aa=48, aac=48)),
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
@@ -78,7 +79,7 @@ def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
 
     clip = clip_format(fmt, w, h)
     cfg = Config(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subw,
-                 subh=clip.subh, **kw)
+                 subh=clip.subh, **{k: v for k, v in kw.items() if k != "isolated_planes"})  # the port has the reference's pool only
     cores = max(1, min(os.cpu_count() or 1, 16))
     src = synth.frame(clip, "noise", seed=1)
     # calibrate on one frame, single thread
@@ -152,7 +153,7 @@ def main():
     out_bytes = frame_in_bytes * (2 if kw.get("dh") else 1)
     per_round = 256 * (8 // waves_per_frame)        # workgroups resident at a time
     fit = (48 << 30) // (frame_in_bytes + out_bytes)
-    if clip.planes >= 3 and clip.subw + clip.subh > 0:  # the 4:2:0 sweeps also need 2 hand-off pools per frame
+    if clip.planes >= 3 and clip.subw + clip.subh > 0 and not kw.get("isolated_planes"):  # the 4:2:0 sweeps also need 2 hand-off pools per frame
         fit = min(fit, (24 << 30) // (2 * 9 * (h // 4 + 3) * waves_per_frame * 64 * 16))
     rounds = max(1, min(4, fit // per_round))
     batch = args.batch or rounds * per_round

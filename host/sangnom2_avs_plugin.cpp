@@ -77,6 +77,7 @@ AVSValue __cdecl Create_SangNom2(AVSValue args, void*, IScriptEnvironment* env)
     a.luma = args[6].AsBool(true);
     a.chroma = args[7].AsBool(true);
     a.opt = args[8].AsInt(-1);
+    a.isolated = args[9].AsBool(false);  // extension, see include/sangnom_hip.h: sn_config.isolated_planes
     return new SangNom2(args[0].AsClip(), a, env, "SangNom2");
 }
 
@@ -96,7 +97,7 @@ extern "C" __declspec(dllexport) const char* __stdcall AvisynthPluginInit3(IScri
                                                                            const AVS_Linkage* const vectors)
 {
     AVS_linkage = vectors;
-    env->AddFunction("SangNom2", "c[order]i[aa]i[aac]i[threads]i[dh]b[luma]b[chroma]b[opt]i", Create_SangNom2, 0);
+    env->AddFunction("SangNom2", "c[order]i[aa]i[aac]i[threads]i[dh]b[luma]b[chroma]b[opt]i[isolated]b", Create_SangNom2, 0);
     env->AddFunction("SangNom", "c[order]i[aa]i[opt]i", Create_SangNom, 0);
     return "SangNom2";
 }

@@ -35,6 +35,7 @@ struct Args {  // SangNom2(clip, order, aa, aac, threads, dh, luma, chroma, opt)
     int opt = -1;     // the reference's CPU code-path switch; validated, otherwise unused
     int device = 0;   // HIP device ordinal (not a script argument)
     int lookahead = -1;  // frames in flight behind GetFrame; -1: $SANGNOM_LOOKAHEAD or 1 (synchronous)
+    bool isolated = false;  // extension: every plane filtered as a Y clip of its own (sn_config.isolated_planes)
 };
 
 template <class Host>
@@ -83,6 +84,7 @@ public:
             la = e ? std::atoi(e) : 1;
         }
         c.host_depth = std::max(1, std::min(la, 256));
+        c.isolated_planes = a.isolated ? 1 : 0;
         const int rc = sn_create(&c, &ctx_);
         if (rc != SN_OK) env->ThrowError("%s: %s", name, sn_last_error(nullptr));
         if (a.dh) Host::SetHeight(vi_, Host::Height(vi_) * 2);  // src/SangNom2.cpp:284-285

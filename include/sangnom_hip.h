@@ -77,6 +77,11 @@ typedef struct sn_config {
     int32_t max_batch;        /* frames one sn_process_device_strided call may carry (>= 1)  */
     int32_t mode;             /* SN_MODE_*                                                   */
     int32_t host_depth;       /* frames sn_submit_host may keep in flight (0 = 4)            */
+    int32_t isolated_planes;  /* EXTENSION, default 0.  1: every plane is filtered as a Y clip *
+                               * of its own (own scratch geometry, nothing shared) -- what    *
+                               * ExtractY/U/V -> SangNom2 -> CombinePlanes gives with the      *
+                               * reference -- instead of the reference's luma-sized pool that *
+                               * subsampled chroma shares with luma (SangNom2.cpp:287-310)    */
     void*   stream;           /* hipStream_t to run on; NULL = the context creates its own   */
 } sn_config;
 

@@ -433,3 +433,42 @@ def test_host_ring_pipelines_frames_like_get_frame(hip_lib, fmt, w, h, kw, depth
     for f in range(N):
         for p in range(len(want[f])):
             assert same(want[f][p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
+
+
+ISOLATED = [
+    ("YUV420P8", 3840, 64, dict(aa=48, aac=48)),        # chroma 1920 wide: 2-wave planes, two frames per workgroup
+    ("YUV420P8", 128, 64, dict(aac=30, order=0)),
+    ("YUV420P16", 256, 48, dict(aac=48)),
+    ("YUV422P8", 576, 28, dict(aac=48, order=2)),
+    ("YUV420PS", 128, 32, dict(aac=48)),                # float with subsampled chroma: fused only when isolated
+    ("YUV420P8", 200, 40, dict(aac=48)),                # luma 200, chroma 100 wide: every plane history-carrying
+    ("YUV420P8", 320, 40, dict(aac=48, dh=True)),       # luma fused, chroma (160 wide) too
+    ("YUV420P8", 192, 32, dict(aac=48, luma=False)),    # luma copied
+    ("YUV420P8", 192, 32, dict(chroma=False)),
+]
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", ISOLATED, ids=[f"{c[0]}-{c[1]}x{c[2]}-{i}" for i, c in enumerate(ISOLATED)])
+def test_isolated_planes_equal_the_filter_applied_to_each_plane_as_a_y_clip(hip_lib, fmt, w, h, kw):
+    """sn_config.isolated_planes (extension): plane p of the result == what the reference gives for that plane
+    fed in as a Y clip of its own (ExtractY/U/V -> SangNom2 -> CombinePlanes), frame after frame."""
+    clip = clip_format(fmt, w, h)
+    N = 3
+    frames = make_frames(clip, "noise", N, seed0=61)
+    oracles = []
+    for p in range(3):
+        yclip = ClipFormat(width=w >> (clip.subw if p else 0), height=h >> (clip.subh if p else 0), bytes=clip.bytes, bits=clip.bits)
+        enabled = kw.get("luma", True) if p == 0 else kw.get("chroma", True)
+        oracles.append(Oracle(oracle_cfg(yclip, order=kw.get("order", 1), aa=kw.get("aa", 48) if p == 0 else kw.get("aac", 0),
+                                         dh=kw.get("dh", False), luma=enabled)))
+    with SangNom2(clip, isolated_planes=True, **kw) as flt:
+        for f in range(N):
+            got = flt.get_frame(frames[f], parity=f & 1)
+            for p in range(3):
+                want = oracles[p].process([frames[f][p]], parity=f & 1)[0]
+                assert same(want, got[p]), f"frame {f} plane {p}: " + describe_diff(want, got[p])
+        info = flt.info()
+        all_mod32 = all((w >> (clip.subw if p else 0)) % 32 == 0 for p in range(3)
+                        if kw.get("dh") or (kw.get("luma", True) if p == 0 else kw.get("chroma", True)))
+        assert info.history_free == int(all_mod32)
+        assert info.fused_eligible == int(all_mod32)
