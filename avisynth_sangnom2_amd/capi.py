@@ -30,7 +30,7 @@ class SnConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "struct_size", "width", "height", "bytes_per_sample", "bits_per_sample", "num_planes",
         "sub_w", "sub_h", "order", "aa", "aac", "dh", "luma", "chroma", "device", "max_batch",
-        "mode", "host_depth", "isolated_planes")] + [("stream", ctypes.c_void_p)]
+        "mode", "host_depth", "isolated_planes", "fresh_pool")] + [("stream", ctypes.c_void_p)]
 
 
 class SnInfo(ctypes.Structure):

@@ -38,6 +38,10 @@ struct Context {
     bool isolated = false;
     PoolArgs plane_pool[3] = {};
     bool plane_fused[3] = {false, false, false};
+    // cfg.fresh_pool: on top of that every frame starts from a zero-filled pool (planes narrower than their pool
+    // stride are swept over the whole stride with zero costs in the padding columns)
+    bool fresh = false;
+    bool plane_padded[3] = {false, false, false};
     int slots = 1;    // frames of a batch the pool path runs at once (1: frames in order on slot 0)
 
     int fslots = 1;   // frames per chunk of the fused 4:2:0 sweeps (each needs its two hand-off pools)
@@ -146,6 +150,7 @@ static const char* structural_text(const sn_config& c)
     if (c.max_batch < 0) return "max_batch must be >= 0";
     if (c.host_depth < 0 || c.host_depth > 256) return "host_depth must be 0..256";
     if (c.isolated_planes != 0 && c.isolated_planes != 1) return "isolated_planes must be 0 or 1";
+    if (c.fresh_pool != 0 && c.fresh_pool != 1) return "fresh_pool must be 0 or 1";
     if (c.mode < SN_MODE_AUTO || c.mode > SN_MODE_FUSED) return "mode must be SN_MODE_AUTO/POOL/FUSED";
     return nullptr;
 }
@@ -273,7 +278,8 @@ static int create_impl(const sn_config* cfg, Context* c)
     if (c->out_height / 2 > 65535)
         return sn::fail(c, SN_ERR_UNSUPPORTED, "height %d exceeds the supported maximum", cfg->height);
     c->history_free = sn::compute_history_free(*c);
-    c->isolated = cfg->isolated_planes != 0 && c->nplanes() > 1;
+    c->fresh = cfg->fresh_pool != 0;
+    c->isolated = c->fresh || (cfg->isolated_planes != 0 && c->nplanes() > 1);
 
     bool eligible = sn::fused_eligible(c->cfg);
     if (c->isolated) {
@@ -288,8 +294,10 @@ static int create_impl(const sn_config* cfg, Context* c)
             pool.bh = (c->plane_h_out(p) + 1) >> 1;
             pool.slot_bytes = ((int64_t)sn::kBuffers * (pool.bh + 1) * pool.stride_e * cfg->bytes_per_sample + 255) & ~(int64_t)255;
             if (!(cfg->dh || c->process[p])) continue;  // copied planes need nothing
-            if (pool.stride_e != c->plane_w(p)) c->history_free = false;
+            if (pool.stride_e != c->plane_w(p) && !c->fresh) c->history_free = false;
             c->plane_fused[p] = sn::fused_plane_eligible(cfg->bytes_per_sample, c->plane_w(p));
+            if (c->fresh && !c->plane_fused[p] && sn::fused_padded_plane_eligible(cfg->bytes_per_sample, c->plane_w(p)))
+                c->plane_fused[p] = c->plane_padded[p] = true;
             eligible = eligible && c->plane_fused[p];
         }
     }
@@ -437,7 +445,19 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         for (int p = 0; p < c->nplanes(); ++p) {
             const sn::PlaneArgs& a = pa[p];
             if (a.enabled && c->plane_fused[p] && sn::fused_layout_ok(a)) {
-                SN_HIP(c, launch_plain_fused(a, p, n));
+                if (c->plane_padded[p]) {
+                    // the sweep of the chroma coupling with nothing to read back: costs are zero outside the plane,
+                    // the box filter clamps at the end of the pool stride (SangNom2.cpp:144-150)
+                    sn::FusedPool fp{};
+                    fp.mode = 2;
+                    fp.sweep_w = c->plane_pool[p].stride_e;
+                    fp.pool_rows = 1;
+                    fp.sweep_rows = a.h_out / 2 - 1;
+                    if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
+                    else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp));
+                } else {
+                    SN_HIP(c, launch_plain_fused(a, p, n));
+                }
                 if (!counted) c->fused_frames += n;
                 counted = true;
                 continue;
@@ -446,9 +466,11 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
             if (!a.enabled) continue;
             const int rc = ensure_pool(c, p);
             if (rc != SN_OK) return rc;
+            const sn::PoolArgs& pool = c->plane_pool[p];
             for (int i = 0; i < n; i += c->slots) {
                 const int m = n - i < c->slots ? n - i : c->slots;
-                SN_HIP(c, sn::launch_pool_plane(st, frames_from(a, i), c->plane_pool[p], c->cfg.bytes_per_sample, c->threshold(p), m, slot0));
+                if (c->fresh) SN_HIP(c, hipMemsetAsync(pool.base + (int64_t)slot0 * pool.slot_bytes, 0, (size_t)pool.slot_bytes * m, st));
+                SN_HIP(c, sn::launch_pool_plane(st, frames_from(a, i), pool, c->cfg.bytes_per_sample, c->threshold(p), m, slot0));
             }
         }
         return SN_OK;
@@ -775,7 +797,9 @@ int sn_get_info(sn_context* h, sn_info* info)
     if (c->isolated) {
         info->fused_eligible = 1;
         for (int p = 0; p < c->nplanes(); ++p)
-            if ((c->cfg.dh || c->process[p]) && !sn::fused_plane_eligible(c->cfg.bytes_per_sample, c->plane_w(p))) info->fused_eligible = 0;
+            if ((c->cfg.dh || c->process[p]) && !sn::fused_plane_eligible(c->cfg.bytes_per_sample, c->plane_w(p)) &&
+                !(c->fresh && sn::fused_padded_plane_eligible(c->cfg.bytes_per_sample, c->plane_w(p))))
+                info->fused_eligible = 0;
     }
     info->history_free = c->history_free ? 1 : 0;
     info->frames = c->frames;

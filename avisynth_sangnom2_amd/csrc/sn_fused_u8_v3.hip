@@ -528,8 +528,8 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         io.row_stride = NW * 64 * 16;
         io.buf_stride = a.pool_rows * io.row_stride;
         if (MODE == kChroma)
-            io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in + (int64_t)f * a.pool_frame_stride), 0,
-                                                       pool_bytes, 0x00020000);
+            io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in ? a.pool_in + (int64_t)f * a.pool_frame_stride : nullptr), 0,
+                                                       a.pool_in ? pool_bytes : 0, 0x00020000);
         io.rout = __builtin_amdgcn_make_buffer_rsrc(a.pool_out ? a.pool_out + (int64_t)f * a.pool_frame_stride : nullptr, 0,
                                                     a.pool_out ? pool_bytes : 0, 0x00020000);
         // the slot a lane reads: its own, or -- for ghost lanes -- the slot of the thread that owns

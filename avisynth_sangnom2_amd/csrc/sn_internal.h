@@ -47,6 +47,8 @@ hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& 
 bool fused_eligible(const sn_config& c);
 // one plane of width w on its own (plain sweep): sample size and width within what the fused kernels take
 bool fused_plane_eligible(int bytes_per_sample, int w);
+// ... swept over its pool stride roundup(w, 32) with zero costs in the padding (fresh_pool; 8- and 16-bit)
+bool fused_padded_plane_eligible(int bytes_per_sample, int w);
 bool fused_needs_pools(const sn_config& c);  // subsampled chroma: luma / chroma sweeps coupled through scratch pools
 bool fused_v2_plane_ok(int w);
 bool fused_layout_ok(const PlaneArgs& p);

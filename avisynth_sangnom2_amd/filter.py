@@ -64,7 +64,7 @@ class SangNom2:
     def __init__(self, clip: ClipFormat, order: int = 1, aa: int = 48, aac: int = 0, threads: int = 0,
                  dh: bool = False, luma: bool = True, chroma: bool = True, opt: int = -1,
                  device: int = 0, max_batch: int = 1, mode: str = "auto", stream: int | None = None,
-                 host_depth: int = 0, isolated_planes: bool = False):
+                 host_depth: int = 0, isolated_planes: bool = False, fresh_pool: bool = False):
         # `threads` is a dummy in the reference (README.md:40-41); `opt` picks its CPU code path.
         if opt < -1 or opt > 1:
             raise SangNomError(capi.SN_ERR_CONFIG, "SangNom2: opt must be between -1..2.")  # sic, SangNom2.cpp:420
@@ -74,7 +74,7 @@ class SangNom2:
             struct_size=ctypes.sizeof(capi.SnConfig), width=clip.width, height=clip.height,
             bytes_per_sample=clip.bytes, bits_per_sample=clip.bits, num_planes=clip.planes,
             sub_w=clip.subw, sub_h=clip.subh, order=order, aa=aa, aac=aac, dh=int(dh), luma=int(luma),
-            chroma=int(chroma), device=device, max_batch=max_batch, mode=capi.MODES[mode], host_depth=host_depth, isolated_planes=int(isolated_planes),
+            chroma=int(chroma), device=device, max_batch=max_batch, mode=capi.MODES[mode], host_depth=host_depth, isolated_planes=int(isolated_planes), fresh_pool=int(fresh_pool),
             stream=stream)
         self._cfg = cfg
         self.max_batch = max_batch

@@ -30,6 +30,9 @@ WORKLOADS = {
     "4320p-Y8": ("Y8", 7680, 4320, dict(order=1, aa=48)),
     "2160p-YUV420P8": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48)),
     "2160p-YUV420P8-isolated": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48, isolated_planes=True)),
+    "480p-YUV420P8": ("YUV420P8", 720, 480, dict(order=1, aa=48, aac=48)),  # width % 32 != 0: history-carrying
+    "480p-YUV420P8-fresh": ("YUV420P8", 720, 480, dict(order=1, aa=48, aac=48, fresh_pool=True)),
+    "2160p-turned-Y8-fresh": ("Y8", 2160, 3840, dict(order=1, aa=48, fresh_pool=True)),
     "2160p-Y16": ("Y16", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420P16": ("YUV420P16", 3840, 2160, dict(order=1, aa=48, aac=48)),
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
@@ -79,7 +82,7 @@ def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
 
     clip = clip_format(fmt, w, h)
     cfg = Config(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subw,
-                 subh=clip.subh, **{k: v for k, v in kw.items() if k != "isolated_planes"})  # the port has the reference's pool only
+                 subh=clip.subh, **{k: v for k, v in kw.items() if k not in ("isolated_planes", "fresh_pool")})  # the port has the reference's pool only
     cores = max(1, min(os.cpu_count() or 1, 16))
     src = synth.frame(clip, "noise", seed=1)
     # calibrate on one frame, single thread
@@ -148,12 +151,13 @@ def main():
     # One fused-kernel workgroup sweeps one plane of one frame; 2048 waves are resident at a time (two per
     # SIMD), and a launch is sized to four such rounds so that uneven workgroup durations even out instead
     # of leaving SIMDs idle at the end of a single round.  Capped at 48 GiB of in + out.
-    strips = 1 if w <= 512 else 1 + -(-(w // 8 - 62) // 60)
+    sweep_w = (w + 31) // 32 * 32
+    strips = 1 if sweep_w <= 512 else 1 + -(-(sweep_w // 8 - 62) // 60)
     waves_per_frame = strips if clip.bytes >= 2 else (strips + 1) // 2
     out_bytes = frame_in_bytes * (2 if kw.get("dh") else 1)
     per_round = 256 * (8 // waves_per_frame)        # workgroups resident at a time
     fit = (48 << 30) // (frame_in_bytes + out_bytes)
-    if clip.planes >= 3 and clip.subw + clip.subh > 0 and not kw.get("isolated_planes"):  # the 4:2:0 sweeps also need 2 hand-off pools per frame
+    if clip.planes >= 3 and clip.subw + clip.subh > 0 and not (kw.get("isolated_planes") or kw.get("fresh_pool")):  # the 4:2:0 sweeps also need 2 hand-off pools per frame
         fit = min(fit, (24 << 30) // (2 * 9 * (h // 4 + 3) * waves_per_frame * 64 * 16))
     rounds = max(1, min(4, fit // per_round))
     batch = args.batch or rounds * per_round

@@ -77,7 +77,8 @@ AVSValue __cdecl Create_SangNom2(AVSValue args, void*, IScriptEnvironment* env)
     a.luma = args[6].AsBool(true);
     a.chroma = args[7].AsBool(true);
     a.opt = args[8].AsInt(-1);
-    a.isolated = args[9].AsBool(false);  // extension, see include/sangnom_hip.h: sn_config.isolated_planes
+    a.isolated = args[9].AsBool(false);  // extensions, see include/sangnom_hip.h: sn_config.isolated_planes,
+    a.fresh = args[10].AsBool(false);    // sn_config.fresh_pool
     return new SangNom2(args[0].AsClip(), a, env, "SangNom2");
 }
 
@@ -97,7 +98,7 @@ extern "C" __declspec(dllexport) const char* __stdcall AvisynthPluginInit3(IScri
                                                                            const AVS_Linkage* const vectors)
 {
     AVS_linkage = vectors;
-    env->AddFunction("SangNom2", "c[order]i[aa]i[aac]i[threads]i[dh]b[luma]b[chroma]b[opt]i[isolated]b", Create_SangNom2, 0);
+    env->AddFunction("SangNom2", "c[order]i[aa]i[aac]i[threads]i[dh]b[luma]b[chroma]b[opt]i[isolated]b[fresh]b", Create_SangNom2, 0);
     env->AddFunction("SangNom", "c[order]i[aa]i[opt]i", Create_SangNom, 0);
     return "SangNom2";
 }

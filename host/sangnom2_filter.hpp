@@ -36,6 +36,7 @@ struct Args {  // SangNom2(clip, order, aa, aac, threads, dh, luma, chroma, opt)
     int device = 0;   // HIP device ordinal (not a script argument)
     int lookahead = -1;  // frames in flight behind GetFrame; -1: $SANGNOM_LOOKAHEAD or 1 (synchronous)
     bool isolated = false;  // extension: every plane filtered as a Y clip of its own (sn_config.isolated_planes)
+    bool fresh = false;     // extension: ... and every frame by a new instance (sn_config.fresh_pool)
 };
 
 template <class Host>
@@ -85,6 +86,7 @@ public:
         }
         c.host_depth = std::max(1, std::min(la, 256));
         c.isolated_planes = a.isolated ? 1 : 0;
+        c.fresh_pool = a.fresh ? 1 : 0;
         const int rc = sn_create(&c, &ctx_);
         if (rc != SN_OK) env->ThrowError("%s: %s", name, sn_last_error(nullptr));
         if (a.dh) Host::SetHeight(vi_, Host::Height(vi_) * 2);  // src/SangNom2.cpp:284-285

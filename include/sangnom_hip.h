@@ -82,6 +82,12 @@ typedef struct sn_config {
                                * ExtractY/U/V -> SangNom2 -> CombinePlanes gives with the      *
                                * reference -- instead of the reference's luma-sized pool that *
                                * subsampled chroma shares with luma (SangNom2.cpp:287-310)    */
+    int32_t fresh_pool;       /* EXTENSION, default 0.  1: every plane of every frame is      *
+                               * filtered as by a newly created reference instance (scratch   *
+                               * zero-filled, planes isolated).  Removes the dependence on     *
+                               * earlier frames that the reference has when the width is not   *
+                               * a multiple of 32, and with it the need to     *
+                               * run such clips frame by frame                                 */
     void*   stream;           /* hipStream_t to run on; NULL = the context creates its own   */
 } sn_config;
 

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _cfg(**kw):
     base = dict(struct_size=ctypes.sizeof(capi.SnConfig), width=64, height=32, bytes_per_sample=1,
                 bits_per_sample=8, num_planes=1, sub_w=0, sub_h=0, order=1, aa=48, aac=0, dh=0, luma=1,
-                chroma=1, device=0, max_batch=1, mode=0, host_depth=0, isolated_planes=0, stream=None)
+                chroma=1, device=0, max_batch=1, mode=0, host_depth=0, isolated_planes=0, fresh_pool=0, stream=None)
     base.update(kw)
     return capi.SnConfig(**base)
 

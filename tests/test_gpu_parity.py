@@ -472,3 +472,46 @@ def test_isolated_planes_equal_the_filter_applied_to_each_plane_as_a_y_clip(hip_
                         if kw.get("dh") or (kw.get("luma", True) if p == 0 else kw.get("chroma", True)))
         assert info.history_free == int(all_mod32)
         assert info.fused_eligible == int(all_mod32)
+
+
+FRESH = [
+    ("YUV420P8", 720, 480, dict(aa=48, aac=48)),      # SD: luma 720 (pool stride 736), chroma 360 (384): padded sweeps
+    ("Y8", 2160, 64, dict(order=2)),                  # a turned 2160p plane: stride 2176
+    ("Y16", 1080, 48, {}),
+    ("Y8", 100, 40, dict(aa=20)),                     # 100 % 8 != 0: pool path over a pool zeroed per frame
+    ("Y32", 720, 32, {}),                             # float: pool path
+    ("YUV420P8", 128, 64, dict(aac=48, order=0)),     # widths that need no padding: plain sweeps
+    ("YUV444P16", 200, 32, dict(aac=48, dh=True)),
+    ("Y8", 7672, 16, {}),                             # stride 7680: the widest padded sweep
+]
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", FRESH, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in FRESH])
+def test_fresh_pool_equals_a_new_instance_per_frame_and_plane(hip_lib, fmt, w, h, kw):
+    """sn_config.fresh_pool (extension): plane p of frame f == the reference's FIRST output frame for that plane
+    fed in as a Y clip; frames run as a batch (no dependence on earlier frames, whatever the width)."""
+    import torch
+    clip = clip_format(fmt, w, h)
+    N = 4
+    frames = make_frames(clip, "noise", N, seed0=81)
+    dev = torch.device("cuda:0")
+    tdt = {np.uint8: torch.uint8, np.uint16: torch.int16, np.float32: torch.float32}[clip.dtype]
+    vt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+    with SangNom2(clip, fresh_pool=True, max_batch=N, **kw) as flt:
+        assert flt.info().history_free == 1
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(vt)).to(dev) for p in range(clip.planes)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
+        torch.cuda.synchronize()
+        parity = [f & 1 for f in range(N)]
+        flt.process_batch(src, dst, parity)
+        flt.synchronize()
+        host_way = flt.get_frame(frames[1], parity=1)
+    for f in range(N):
+        for p in range(clip.planes):
+            yclip = ClipFormat(width=w >> (clip.subw if p else 0), height=h >> (clip.subh if p else 0), bytes=clip.bytes, bits=clip.bits)
+            ora = Oracle(oracle_cfg(yclip, order=kw.get("order", 1), aa=kw.get("aa", 48) if p == 0 else kw.get("aac", 0), dh=kw.get("dh", False)))
+            want = ora.process([frames[f][p]], parity=parity[f])[0]
+            got = dst[p][f].cpu().numpy().view(clip.dtype)
+            assert same(want, got), f"frame {f} plane {p}: " + describe_diff(want, got)
+            if f == 1:
+                assert same(want, host_way[p]), f"host path, plane {p}"
