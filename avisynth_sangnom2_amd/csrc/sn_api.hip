@@ -446,10 +446,10 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
             const sn::PlaneArgs& a = pa[p];
             if (a.enabled && c->plane_fused[p] && sn::fused_layout_ok(a)) {
                 if (c->plane_padded[p]) {
-                    // the sweep of the chroma coupling with nothing to read back: costs are zero outside the plane,
-                    // the box filter clamps at the end of the pool stride (SangNom2.cpp:144-150)
+                    // the sweep covers the whole pool stride: costs are zero outside the plane, the box filter clamps
+                    // at the end of the stride (SangNom2.cpp:144-150)
                     sn::FusedPool fp{};
-                    fp.mode = 2;
+                    fp.mode = 3;  // kPadded
                     fp.sweep_w = c->plane_pool[p].stride_e;
                     fp.pool_rows = 1;
                     fp.sweep_rows = a.h_out / 2 - 1;

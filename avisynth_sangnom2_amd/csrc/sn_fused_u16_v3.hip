@@ -186,6 +186,10 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
 #pragma unroll
             for (int j = 0; j < PXL; ++j) D[j] = role.inside ? cost<BUF>(n, nn, j) : D[j];
         }
+    } else if constexpr (MODE == kPadded) {
+        const unsigned inside = role.inside ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) D[j] = S1 ? (cost<BUF>(n, nn, j) & inside) : 0u;
     } else {
 #pragma unroll
         for (int j = 0; j < PXL; ++j) D[j] = S1 ? cost<BUF>(n, nn, j) : 0u;
@@ -201,10 +205,10 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
         A[j] = O[j] + D[j];
         kmin[j] = umin(kmin[j], t | rank_of<BUF>());
     }
-    if constexpr (MODE != kPlain) io.store(BUF, rc.r, rc.vout, O);
+    if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
 }
 
-__host__ __device__ constexpr int reg_buffers(int mode) { return mode == 0 ? 6 : 4; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 6; }
 
 template <int NT, int RB>
 struct Parked {
@@ -363,7 +367,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     const bool live = gl < a.nl;
     const bool real = live && !ghost;
     const int x0 = gl * PXL;
-    const int line_w = MODE == kChroma ? a.region_w : a.w;
+    const int line_w = has_region(MODE) ? a.region_w : a.w;
     const bool line_live = live && x0 < line_w;
     const bool line_real = real && x0 < line_w;
     LaneRole role;
@@ -403,7 +407,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     auto put = [&](int row_off, const Out& o) { store_b128(o.v, rd, vstore, row_off); };
 
     PoolIO io{};
-    if constexpr (MODE != kPlain) {
+    if constexpr (has_pools(MODE)) {
         const int pool_bytes = kBuffers * a.pool_rows * NT * 16;
         io.row_stride = NT * 16;
         io.buf_stride = a.pool_rows * io.row_stride;
@@ -444,6 +448,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) Ab[j] = role.inside ? cost<B>(L0, L1, j) : Ab[j];
             }
+        } else if constexpr (MODE == kPadded) {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) Ab[j] = (nr > 0 && role.inside) ? cost<B>(L0, L1, j) : 0u;
         } else {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? cost<B>(L0, L1, j) : 0u;
@@ -523,7 +530,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         RowCtx rc;
         rc.r = r;
         rc.next_ok = r + 1 <= a.rows_in;
-        rc.vout = (MODE != kPlain && r <= a.rows_out) ? io.v_out : kOutOfRange;
+        rc.vout = (has_pools(MODE) && r <= a.rows_out) ? io.v_out : kOutOfRange;
         pending = row_step<MODE, S1, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c
         if (r < sweep && r % K == 0) {
@@ -649,6 +656,7 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.region_w = p.w;
     a.sweep_rows = pool->sweep_rows;
     if (pool->mode == v3c::kLumaSpill) return w16::launch_mode<v3c::kLumaSpill>(st, a, nframes);
+    if (pool->mode == v3c::kPadded) return w16::launch_mode<v3c::kPadded>(st, a, nframes);
     return w16::launch_mode<v3c::kChroma>(st, a, nframes);
 }
 

@@ -252,6 +252,9 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
 #pragma unroll
             for (int j = 0; j < PXL; ++j) D[j] = bfi(role.inside_mask, cost<BUF>(n, nn, j), D[j]);
         }
+    } else if constexpr (MODE == kPadded) {
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) D[j] = S1 ? (cost<BUF>(n, nn, j) & role.inside_mask) : 0u;
     } else {
 #pragma unroll
         for (int j = 0; j < PXL; ++j) D[j] = S1 ? cost<BUF>(n, nn, j) : 0u;
@@ -267,7 +270,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
         A[j] = O[j] + D[j];                      // O + D[r+1]
         kmin[j] = pk_min(kmin[j], t | rank_of<BUF>());
     }
-    if constexpr (MODE != kPlain) io.store(BUF, rc.r, rc.vout, O);
+    if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
 }
 
 struct Out {
@@ -281,7 +284,7 @@ struct Out {
 // Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
 // The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
 // in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
-__host__ __device__ constexpr int reg_buffers(int mode) { return mode == 0 ? 6 : 4; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 6; }
 template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     role.last_mask = 0;
     role.line_last_mask = 0;
     role.inside_mask = 0;
-    const int line_w = MODE == kChroma ? a.region_w : a.w;  // width of the source / destination plane
+    const int line_w = has_region(MODE) ? a.region_w : a.w;  // width of the source / destination plane
     bool line_live[2], line_real[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -523,7 +526,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
 
     // scratch pools of the chroma coupling
     PoolIO io{};
-    if constexpr (MODE != kPlain) {
+    if constexpr (has_pools(MODE)) {
         const int pool_bytes = kBuffers * a.pool_rows * NW * 64 * 16;
         io.row_stride = NW * 64 * 16;
         io.buf_stride = a.pool_rows * io.row_stride;
@@ -577,6 +580,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) Ab[j] = bfi(role.inside_mask, cost<B>(L0, L1, j), Ab[j]);
             }
+        } else if constexpr (MODE == kPadded) {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? (cost<B>(L0, L1, j) & role.inside_mask) : 0u;
         } else {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? cost<B>(L0, L1, j) : 0u;
@@ -664,7 +670,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         RowCtx rc;
         rc.r = r;
         rc.next_ok = r + 1 <= a.rows_in;
-        rc.vout = (MODE != kPlain && r <= a.rows_out) ? io.v_out : kOutOfRange;
+        rc.vout = (has_pools(MODE) && r <= a.rows_out) ? io.v_out : kOutOfRange;
         pending = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
         if (r < sweep) {
@@ -828,6 +834,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.region_w = p.w;
     a.sweep_rows = pool->sweep_rows;
     if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
+    if (pool->mode == v3::kPadded) return launch_mode<v3::kPadded>(st, a, nframes);
     return launch_mode<v3::kChroma>(st, a, nframes);
 }
 

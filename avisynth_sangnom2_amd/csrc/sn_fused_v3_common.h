@@ -62,7 +62,11 @@ struct Args {
 //               pass's O read back from the pool; stage 3 and the output exist only inside the region.
 // Pool layout: [buffer][row][thread][4 dwords], dword k = O[2k] | O[2k+1] << 8 (packed pairs), i.e. every
 // thread re-reads what the thread with the same columns wrote; ghost lanes read their owner's slot.
-enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2 };
+//   kPadded     a plane narrower than its pool stride on a zero-filled pool (sn_config.fresh_pool): the sweep covers
+//               the whole stride, costs are zero in the padding columns, nothing is read back or left behind.
+enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2, kPadded = 3 };
+__host__ __device__ constexpr bool has_region(int mode) { return mode == kChroma || mode == kPadded; }  // lines narrower than the sweep
+__host__ __device__ constexpr bool has_pools(int mode) { return mode == kLumaSpill || mode == kChroma; }
 
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));

@@ -57,7 +57,7 @@ hipError_t launch_fused_u8(hipStream_t s, const PlaneArgs& p, double threshold, 
 bool fused_v3_plane_ok(int w);
 // Scratch-pool coupling between the luma sweep and the subsampled-chroma sweeps (sn_fused_u8_v3.hip, Mode).
 struct FusedPool {
-    int mode;                // 1 = luma sweep that leaves its smoothed rows, 2 = chroma sweep
+    int mode;                // 1 = luma sweep that leaves its smoothed rows, 2 = chroma sweep, 3 = padded plane (no pools)
     int sweep_w;             // luma width (the pool's width)
     const uint8_t* pool_in;  // chroma: what the previous pass left
     uint8_t* pool_out;       // luma / first chroma pass: where this pass leaves its rows (may be null)
