@@ -19,6 +19,8 @@ import sys
 import threading
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -75,30 +77,44 @@ def recorded_traffic(workload: str, batch: int):
 
 
 def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
-    """The CPU oracle (a scalar port of the reference's opt=0 path) timed on this box's host cores:
-    one context per thread (the reference's MT_MULTI_INSTANCE model), bounded sample."""
+    """A CPU port of the reference's path timed on this box's host cores, one filter instance per thread (the
+    reference's MT_MULTI_INSTANCE model), bounded sample.  For 8-bit Y clips on an AVX2 host this is
+    oracle/sangnom_vec.c -- the oracle's arithmetic written so that gcc vectorises it, standing in for the
+    reference's opt=1 SSE2 path (which cannot be built here) -- otherwise the scalar oracle."""
     from avisynth_sangnom2_amd import clip_format, synth
-    from oracle.oracle import Config, Oracle
+    from oracle.oracle import Config, Oracle, VecOracleY8, vec_lib
 
     clip = clip_format(fmt, w, h)
-    cfg = Config(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subw,
-                 subh=clip.subh, **{k: v for k, v in kw.items() if k not in ("isolated_planes", "fresh_pool")})  # the port has the reference's pool only
     cores = max(1, min(os.cpu_count() or 1, 16))
     src = synth.frame(clip, "noise", seed=1)
+    vec = fmt == "Y8" and not kw.get("dh") and not kw.get("fresh_pool") and vec_lib() is not None
+    if vec:
+        def make():
+            o = VecOracleY8(w, h, kw.get("order", 1), kw.get("aa", 48))
+            return o, (lambda d, o=o: o.process(src[0], dst=d[0]))
+        label = "vectorised port (oracle/sangnom_vec.c, gcc -O3 -mavx2, opt=0 arithmetic)"
+    else:
+        cfg = Config(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subw, subh=clip.subh,
+                     **{k: v for k, v in kw.items() if k not in ("isolated_planes", "fresh_pool")})  # the reference's pool only
+        def make():
+            o = Oracle(cfg)
+            return o, (lambda d, o=o: o.process(src, dst=d))
+        label = "scalar port (oracle/sangnom_oracle.c)"
+    out_h = h * 2 if kw.get("dh") else h
+    proto = [np.zeros((out_h >> (clip.subh if p else 0), w >> (clip.subw if p else 0)), dtype=clip.dtype) for p in range(min(clip.planes, 3))]
     # calibrate on one frame, single thread
-    o = Oracle(cfg)
-    dst = o.process(src)
+    o, run = make()
+    run(proto)
     t0 = time.perf_counter()
-    o.process(src, dst=dst)
+    run(proto)
     one = time.perf_counter() - t0
-    per_thread = max(1, int(seconds_target / max(one, 1e-3)))
-    per_thread = min(per_thread, 64)
-    oracles = [Oracle(cfg) for _ in range(cores)]
-    dsts = [[d.copy() for d in dst] for _ in range(cores)]
+    per_thread = min(max(1, int(seconds_target / max(one, 1e-3))), 2048)
+    workers = [make() for _ in range(cores)]
+    dsts = [[d.copy() for d in proto] for _ in range(cores)]
 
     def work(i):
         for _ in range(per_thread):
-            oracles[i].process(src, dst=dsts[i])
+            workers[i][1](dsts[i])
 
     ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
@@ -108,10 +124,9 @@ def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
         t.join()
     dt = time.perf_counter() - t0
     frames = cores * per_thread
-    out_h = h * 2 if kw.get("dh") else h
     return {"value": round(frames * w * out_h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} frames of {fmt} {w}x{h} uniform noise, {cores} threads x {per_thread} frames, "
-                      f"one oracle context per thread ({dt:.1f} s; single-thread {one * 1e3:.0f} ms/frame)"}
+            "sample": f"{label}: {frames} frames of {fmt} {w}x{h} uniform noise, {cores} threads x {per_thread} frames, "
+                      f"one filter instance per thread ({dt:.1f} s; single-thread {one * 1e3:.0f} ms/frame)"}
 
 
 def main():

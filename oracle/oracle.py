@@ -157,3 +157,67 @@ class Oracle:
         if rc:
             raise RuntimeError(f"sno_process failed: {rc}")
         return dst
+
+
+# ---- the vectorisable 8-bit port (oracle/sangnom_vec.c): CPU timing baseline, bit-identical to the oracle ----
+_VEC_PATH = os.path.join(_HERE, "libsangnom_vec.so")
+_vec = None
+
+
+def cpu_has_avx2() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            return " avx2" in f.read()
+    except OSError:
+        return False
+
+
+def vec_lib():
+    """libsangnom_vec.so, or None where it cannot run (no AVX2) or be built."""
+    global _vec
+    if _vec is None:
+        if not cpu_has_avx2():
+            return None
+        src = os.path.join(_HERE, "sangnom_vec.c")
+        if not os.path.exists(_VEC_PATH) or os.path.getmtime(src) > os.path.getmtime(_VEC_PATH):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libsangnom_vec.so"])
+        L = ctypes.CDLL(_VEC_PATH)
+        L.snv_create_y8.restype = ctypes.c_void_p
+        L.snv_create_y8.argtypes = [ctypes.c_int] * 4
+        L.snv_destroy.argtypes = [ctypes.c_void_p]
+        L.snv_pool.restype = ctypes.c_void_p
+        L.snv_pool.argtypes = [ctypes.c_void_p]
+        L.snv_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        _vec = L
+    return _vec
+
+
+class VecOracleY8:
+    """One filter instance for an 8-bit Y clip (no dh), same conventions as Oracle."""
+
+    def __init__(self, width: int, height: int, order: int = 1, aa: int = 48):
+        self._lib = vec_lib()
+        if self._lib is None:
+            raise RuntimeError("libsangnom_vec.so needs AVX2")
+        self.w, self.h = width, height
+        self._h = self._lib.snv_create_y8(width, height, order, aa)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.snv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def pool(self) -> np.ndarray:
+        se, bh = (self.w + 31) // 32 * 32, (self.h + 1) >> 1
+        buf = (ctypes.c_uint8 * (9 * (bh + 1) * se)).from_address(self._lib.snv_pool(self._h))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(9, bh + 1, se).copy()
+
+    def process(self, src: np.ndarray, parity: int = 1, dst: np.ndarray | None = None) -> np.ndarray:
+        if dst is None:
+            dst = np.zeros_like(src)
+        assert src.dtype == np.uint8 and src.shape == (self.h, self.w) and src.strides[1] == 1 and dst.strides[1] == 1
+        self._lib.snv_process(self._h, src.ctypes.data, src.strides[0], dst.ctypes.data, dst.strides[0], int(parity))
+        return dst

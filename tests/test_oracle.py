@@ -218,3 +218,19 @@ def test_chroma_sees_stale_luma_pool():
     assert full[1].shape == alone[0].shape
     assert not np.array_equal(full[1], alone[0])
     assert (full[1] != alone[0]).mean() < 0.05
+
+
+@pytest.mark.parametrize("w,h,order,aa", [(64, 32, 1, 48), (100, 40, 0, 20), (1920, 64, 2, 128), (200, 38, 1, 0), (3840, 48, 1, 48)])
+def test_vectorised_port_is_bit_identical_to_the_oracle(w, h, order, aa):
+    """oracle/sangnom_vec.c (the CPU timing baseline of bench.py) against the scalar oracle: output and pool,
+    three frames on one instance each (history carries for widths that are not a multiple of 32)."""
+    from oracle.oracle import VecOracleY8, vec_lib
+    if vec_lib() is None:
+        pytest.skip("no AVX2 on this host")
+    clip = clip_format("Y8", w, h)
+    o, v = Oracle(Config(width=w, height=h, order=order, aa=aa)), VecOracleY8(w, h, order, aa)
+    for f in range(3):
+        src = synth.frame(clip, ("noise", "checker", "edges")[f], seed=f)
+        a, b = o.process(src, parity=f & 1)[0], v.process(src[0], parity=f & 1)
+        assert np.array_equal(a, b), f"frame {f}"
+        assert np.array_equal(o.pool(), v.pool()), f"pool after frame {f}"
