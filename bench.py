@@ -37,6 +37,7 @@ WORKLOADS = {
     "2160p-turned-Y8-fresh": ("Y8", 2160, 3840, dict(order=1, aa=48, fresh_pool=True)),
     "2160p-Y16": ("Y16", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420P16": ("YUV420P16", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "2160p-YUV420P16-dh": ("YUV420P16", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
     "2160p-Y32": ("Y32", 3840, 2160, dict(order=1, aa=48)),
 }
@@ -173,7 +174,7 @@ def main():
     per_round = 256 * (8 // waves_per_frame)        # workgroups resident at a time
     fit = (48 << 30) // (frame_in_bytes + out_bytes)
     if clip.planes >= 3 and clip.subw + clip.subh > 0 and not (kw.get("isolated_planes") or kw.get("fresh_pool")):  # the 4:2:0 sweeps also need 2 hand-off pools per frame
-        fit = min(fit, (24 << 30) // (2 * 9 * (h // 4 + 3) * waves_per_frame * 64 * 16))
+        fit = min(fit, (24 << 30) // (2 * 9 * ((h * (2 if kw.get("dh") else 1)) // 4 + 3) * waves_per_frame * 64 * 16))
     rounds = max(1, min(4, fit // per_round))
     batch = args.batch or rounds * per_round
     stream = torch.cuda.Stream(dev)  # a real (non-null) HIP stream shared with the context, so that

@@ -330,8 +330,9 @@ def test_full_size_fused_equals_pool_and_oracle(hip_lib, name, fmt, w, h, kw, N)
 
 
 @pytest.mark.parametrize("fmt,w,h,kw", [("YUV420P16", 3840, 2160, dict(aa=48, aac=48)),
+                                        ("YUV420P16", 3840, 1080, dict(aa=48, aac=48, dh=True)),
                                         ("YUV444PS", 3840, 1080, dict(aa=48, aac=48, dh=True))],
-                         ids=["2160p YUV420P16", "2160p-out YUV444PS dh"])
+                         ids=["2160p YUV420P16", "2160p-out YUV420P16 dh", "2160p-out YUV444PS dh"])
 def test_full_size_16bit_and_float_match_oracle(hip_lib, fmt, w, h, kw):
     """BASELINE configuration 4 at full size, one frame each, against the oracle (float: bit patterns)."""
     clip = clip_format(fmt, w, h)
