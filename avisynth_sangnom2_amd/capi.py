@@ -22,7 +22,7 @@ EXPORTS = (
     "sn_abi_version", "sn_validate", "sn_create", "sn_destroy", "sn_last_error",
     "sn_process_host", "sn_process_device", "sn_process_device_strided", "sn_synchronize",
     "sn_get_stream", "sn_get_info", "sn_debug_read_pool", "sn_debug_read_coupled_rows",
-    "sn_host_slots", "sn_submit_host", "sn_collect_host",
+    "sn_host_slots", "sn_submit_host", "sn_collect_host", "sn_turn_device",
 )
 
 
@@ -92,6 +92,7 @@ def load():
     L.sn_process_host.argtypes = [vp, p3v, p3i, p3v, p3i, i32]
     L.sn_process_device.argtypes = [vp, p3v, p3i, p3v, p3i, i32]
     L.sn_host_slots.argtypes = [vp]
+    L.sn_turn_device.argtypes = [vp, i32, i32, vp, ctypes.c_int64, i32, i32, i32, vp, ctypes.c_int64, i32]
     L.sn_submit_host.argtypes = [vp, p3v, p3i, i32, ctypes.POINTER(i32)]
     L.sn_collect_host.argtypes = [vp, i32, p3v, p3i]
     L.sn_process_device_strided.argtypes = [vp, i32, p3v, p3l, p3i, p3v, p3l, p3i, p3i]

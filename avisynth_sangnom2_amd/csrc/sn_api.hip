@@ -767,6 +767,22 @@ int sn_collect_host(sn_context* h, int32_t slot, void* const dst[3], const int32
     return SN_OK;
 }
 
+int sn_turn_device(sn_context* h, int32_t direction, int32_t nframes, const void* src, int64_t sfs, int32_t sp, int32_t width,
+                   int32_t height, void* dst, int64_t dfs, int32_t dp)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    const int B = c->cfg.bytes_per_sample;
+    if (!src || !dst || direction == 0 || nframes < 0 || width <= 0 || height <= 0)
+        return sn::fail(c, SN_ERR_INVALID_ARG, "sn_turn_device: bad pointer, direction or size");
+    if (sp < width * B || dp < height * B || sp % B || dp % B || (uintptr_t)src % B || (uintptr_t)dst % B)
+        return sn::fail(c, SN_ERR_INVALID_ARG, "sn_turn_device: pitch smaller than the row or misaligned");
+    SN_HIP(c, hipSetDevice(c->device));
+    SN_HIP(c, sn::launch_turn(c->stream, B, direction > 0 ? 1 : 0, nframes, static_cast<const uint8_t*>(src), sfs, sp, width, height,
+                              static_cast<uint8_t*>(dst), dfs, dp));
+    return SN_OK;
+}
+
 int sn_synchronize(sn_context* h)
 {
     Context* c = reinterpret_cast<Context*>(h);

@@ -37,6 +37,10 @@ struct PoolArgs {
 
 struct Context;
 
+// sn_turn.hip: quarter turn of a plane (right = clockwise), for device-resident anti-aliasing pipelines
+hipError_t launch_turn(hipStream_t s, int bytes, int right, int nframes, const uint8_t* src, int64_t src_frame_stride, int src_pitch, int w,
+                       int h, uint8_t* dst, int64_t dst_frame_stride, int dst_pitch);
+
 // sn_pool_kernels.hip: the three-kernel path over the HBM-resident pool (every format).
 hipError_t launch_assemble(hipStream_t s, const PlaneArgs& p, int bytes, int nframes);
 hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes,

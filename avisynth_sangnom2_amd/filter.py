@@ -192,6 +192,16 @@ class SangNom2:
         self._check(self._lib.sn_collect_host(self._h, int(slot), dp, dpi))
         return dst
 
+    def turn(self, src, dst, direction: int):
+        """TurnRight (direction > 0) / TurnLeft (< 0) of device planes: src [N, H, W] -> dst [N, W, H] (torch tensors)."""
+        B = self.clip.bytes
+        N, H, W = src.shape
+        if tuple(dst.shape) != (N, W, H) or src.stride(2) != 1 or dst.stride(2) != 1 or src.element_size() != B or dst.element_size() != B:
+            raise ValueError("turn: dst must be [N, W, H] of the clip's sample type, both x-contiguous")
+        self._check(self._lib.sn_turn_device(self._h, int(direction), N, src.data_ptr(), src.stride(0) * B, src.stride(1) * B, W, H,
+                                             dst.data_ptr(), dst.stride(0) * B, dst.stride(1) * B))
+        return dst
+
     def get_frame_device(self, src, dst, parity: int = 1):
         """Device planes: torch tensors [H, W] on this context's GPU.  Asynchronous."""
         return self.process_batch([s.unsqueeze(0) for s in src], [d.unsqueeze(0) for d in dst], [parity])
@@ -232,3 +242,51 @@ def SangNom(clip: ClipFormat, order: int = 1, aa: int = 48, opt: int = -1, **kw)
     if order < 0 or order > 2:
         raise SangNomError(capi.SN_ERR_CONFIG, "SangNom: order must be between 0..2.")
     return SangNom2(clip, order=(2, 1, 0)[order], aa=aa, aac=0, opt=opt, **kw)
+
+
+class SangNomAA:
+    """The anti-aliasing idiom TurnLeft().SangNom2(...).TurnRight().SangNom2(...) with the frames kept on the
+    device between the two passes: two filter instances -- one for the turned clip, one for the
+    clip itself -- on one stream, and the library's turn kernel in between.  Not a function of the reference; the
+    result is what that script gives with it."""
+
+    def __init__(self, clip: ClipFormat, max_batch: int = 1, device: int = 0, **kw):
+        self.clip = clip
+        turned = ClipFormat(width=clip.height, height=clip.width, bytes=clip.bytes, bits=clip.bits, planes=clip.planes,
+                            subw=clip.subh, subh=clip.subw)
+        self.first = SangNom2(turned, max_batch=max_batch, device=device, **kw)
+        self.second = SangNom2(clip, max_batch=max_batch, device=device, stream=self.first.stream_handle(), **kw)
+        self._tmp = None
+
+    def close(self):
+        self.second.close()
+        self.first.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def process_batch(self, src, dst, parity=None):
+        """src[p], dst[p]: torch tensors [N, H_p, W_p] on the device.  Asynchronous on the instances' stream."""
+        import torch
+        n = self.first.nplanes
+        N = src[0].shape[0]
+        if self._tmp is None or self._tmp[0][0].shape[0] != N:
+            mk = lambda shape, like: torch.empty((N,) + tuple(shape), dtype=like.dtype, device=like.device)
+            self._tmp = ([mk(self.first.plane_shape_in(p), src[p]) for p in range(n)],
+                         [mk(self.first.plane_shape_out(p), src[p]) for p in range(n)],
+                         [mk(self.second.plane_shape_in(p), src[p]) for p in range(n)])
+            # the buffers were allocated on torch's current stream; the library runs on its own
+            torch.cuda.current_stream().synchronize()
+        t1, u1, t2 = self._tmp
+        for p in range(n):
+            self.first.turn(src[p], t1[p], -1)
+        self.first.process_batch(t1, u1, parity)
+        for p in range(n):
+            self.first.turn(u1[p], t2[p], +1)
+        return self.second.process_batch(t2, dst, parity)
+
+    def synchronize(self):
+        self.second.synchronize()

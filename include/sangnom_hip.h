@@ -155,6 +155,14 @@ int sn_submit_host(sn_context* ctx, const void* const src[3], const int32_t src_
                    int32_t* slot);
 int sn_collect_host(sn_context* ctx, int32_t slot, void* const dst[3], const int32_t dst_pitch[3]);
 
+/* TurnRight (direction > 0, clockwise) / TurnLeft (direction < 0) of `nframes` device-resident planes of
+ * width x height samples of the context's sample type, on the context's stream: dst is height wide and width
+ * high.  For pipelines that keep frames on the GPU between the two SangNom2 passes of an anti-aliasing script
+ * (TurnLeft().SangNom2().TurnRight().SangNom2()).  No counterpart in the reference. */
+int sn_turn_device(sn_context* ctx, int32_t direction, int32_t nframes, const void* src, int64_t src_frame_stride,
+                   int32_t src_pitch, int32_t width, int32_t height, void* dst, int64_t dst_frame_stride,
+                   int32_t dst_pitch);
+
 int sn_synchronize(sn_context* ctx);
 void* sn_get_stream(sn_context* ctx); /* the hipStream_t the context launches on */
 int sn_get_info(sn_context* ctx, sn_info* info);

@@ -10,7 +10,7 @@ from contextlib import nullcontext as _nullcontext
 import numpy as np
 import pytest
 
-from avisynth_sangnom2_amd import ClipFormat, SangNom2, SangNomError, clip_format, synth
+from avisynth_sangnom2_amd import ClipFormat, SangNom2, SangNomAA, SangNomError, clip_format, synth
 from oracle.oracle import Oracle
 from oracle.sangnom_numpy import NumpySangNom
 from tests.util import describe_diff, make_frames, oracle_cfg, same
@@ -516,3 +516,66 @@ def test_fresh_pool_equals_a_new_instance_per_frame_and_plane(hip_lib, fmt, w, h
             assert same(want, got), f"frame {f} plane {p}: " + describe_diff(want, got)
             if f == 1:
                 assert same(want, host_way[p]), f"host path, plane {p}"
+
+
+@pytest.mark.parametrize("fmt,w,h", [("Y8", 200, 136), ("Y8", 64, 64), ("Y16", 70, 33), ("Y32", 129, 66), ("Y8", 3840, 2160)])
+def test_turn_device_is_avisynths_turnright_turnleft(hip_lib, fmt, w, h):
+    import torch
+    clip = clip_format(fmt, w, h)
+    dev = torch.device("cuda:0")
+    vt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+    a = np.stack([synth.frame(clip, "noise", seed=s)[0] for s in range(2)])
+    with SangNom2(ClipFormat(width=64, height=32, bytes=clip.bytes, bits=clip.bits)) as flt:
+        src = torch.from_numpy(a.view(vt)).to(dev)
+        for direction, k in ((+1, -1), (-1, 1)):  # TurnRight = clockwise = rot90(k=-1)
+            dst = torch.zeros((2, w, h), dtype=src.dtype, device=dev)
+            torch.cuda.synchronize()
+            flt.turn(src, dst, direction)
+            flt.synchronize()
+            assert np.array_equal(dst.cpu().numpy().view(clip.dtype), np.rot90(a, k=k, axes=(1, 2)))
+
+
+AA_CASES = [("Y8", 128, 64, dict(aa=48)), ("YUV420P8", 128, 64, dict(aa=48, aac=48)), ("Y16", 96, 64, dict(aa=30, order=2)),
+            ("Y32", 64, 32, {}), ("Y8", 96, 80, dict(aa=48)), ("YUV422P8", 128, 64, dict(aac=48)),
+            ("Y8", 96, 80, dict(aa=48, fresh_pool=True))]
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", AA_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}-{i}" for i, c in enumerate(AA_CASES)])
+def test_anti_aliasing_idiom_on_the_device(hip_lib, fmt, w, h, kw):
+    """TurnLeft().SangNom2().TurnRight().SangNom2() with the frames staying on the device == the same script with
+    two oracle instances and numpy turns, frame after frame (96x80: the turned clip is 80 wide, so the first
+    instance carries pool state from frame to frame)."""
+    import torch
+    clip = clip_format(fmt, w, h)
+    turned = ClipFormat(width=h, height=w, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subh, subh=clip.subw)
+    N = 3
+    frames = make_frames(clip, "noise", N, seed0=91)
+    fresh = kw.get("fresh_pool", False)
+    okw = {k: v for k, v in kw.items() if k != "fresh_pool"}
+
+    def oracle_pass(c, planes, state):
+        if not fresh:
+            return state.setdefault(id(c), Oracle(oracle_cfg(c, **okw))).process(planes)
+        out = []
+        for p, pl in enumerate(planes):  # every plane of every frame on a new instance
+            y = ClipFormat(width=pl.shape[1], height=pl.shape[0], bytes=c.bytes, bits=c.bits)
+            out.append(Oracle(oracle_cfg(y, order=okw.get("order", 1), aa=okw.get("aa", 48) if p == 0 else okw.get("aac", 0))).process([pl])[0])
+        return out
+
+    state = {}
+    want = []
+    for fr in frames:
+        a = oracle_pass(turned, [np.ascontiguousarray(np.rot90(pl, k=1)) for pl in fr], state)
+        want.append(oracle_pass(clip, [np.ascontiguousarray(np.rot90(pl, k=-1)) for pl in a], state))
+    dev = torch.device("cuda:0")
+    vt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+    with SangNomAA(clip, max_batch=N, **kw) as aa:
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(vt)).to(dev) for p in range(clip.planes)]
+        dst = [torch.zeros_like(s) for s in src]
+        torch.cuda.synchronize()
+        aa.process_batch(src, dst)
+        aa.synchronize()
+    for f in range(N):
+        for p in range(clip.planes):
+            got = dst[p][f].cpu().numpy().view(clip.dtype)
+            assert same(want[f][p], got), f"frame {f} plane {p}: " + describe_diff(want[f][p], got)
