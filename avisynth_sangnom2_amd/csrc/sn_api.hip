@@ -453,7 +453,8 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
                     fp.sweep_w = c->plane_pool[p].stride_e;
                     fp.pool_rows = 1;
                     fp.sweep_rows = a.h_out / 2 - 1;
-                    if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
+                    if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, fp.sweep_w));
+                    else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
                     else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp));
                 } else {
                     SN_HIP(c, launch_plain_fused(a, p, n));

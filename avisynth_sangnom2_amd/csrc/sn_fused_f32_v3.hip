@@ -44,7 +44,9 @@ struct Raw {  // pixels x0-4 .. x0+11 as 16 dwords
 struct LaneRole {
     bool edge_wave;  // wave holds the first or last column
     bool first;      // lane owns column 0
-    bool last;       // lane owns the last column
+    bool last;       // lane owns the last column of the sweep
+    bool line_last;  // lane owns the last column of the source lines (PADDED: region_w - 1)
+    float inside;    // PADDED: 1 where the lane's columns belong to the plane, 0 in the padding
     unsigned first_mask, last_mask;  // all ones where first / last
 };
 
@@ -73,7 +75,7 @@ __device__ __forceinline__ void unpack(Line& L, const Raw& q, const LaneRole& ro
     for (int i = 0; i < PXL + 6; ++i) L.P[i] = flt(d[i + 1]);
     if (role.edge_wave) {  // loadPixel's clamp, SangNom2.cpp:25-34
         if (role.first) L.P[0] = L.P[1] = L.P[2] = L.P[3];
-        if (role.last) L.P[11] = L.P[12] = L.P[13] = L.P[10];
+        if (role.line_last) L.P[11] = L.P[12] = L.P[13] = L.P[10];
     }
     sangnom_values(L);
 }
@@ -136,13 +138,16 @@ __device__ __forceinline__ void box7(const float (&S)[PXL], float (&Bx)[PXL], co
         Bx[j] = (((((X[j] + X[j + 1]) + X[j + 2]) + X[j + 3]) + X[j + 4]) + X[j + 5]) + X[j + 6];
 }
 
-template <int BUF, bool S1>
+// PADDED: a plane narrower than its pool stride on a zero-filled pool (sn_config.fresh_pool, see Mode kPadded in
+// sn_fused_v3_common.h): costs are zero in the padding columns -- a multiplication by 1 or 0 (costs are finite and
+// not negative, so that is exact).
+template <int BUF, bool S1, bool PADDED>
 __device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL], unsigned (&rank)[PXL], const Line& n,
                                             const Line& nn, const LaneRole& role)
 {
     float D[PXL], S[PXL], Bx[PXL];
 #pragma unroll
-    for (int j = 0; j < PXL; ++j) D[j] = S1 ? cost<BUF>(n, nn, j) : 0.0f;
+    for (int j = 0; j < PXL; ++j) D[j] = S1 ? (PADDED ? cost<BUF>(n, nn, j) * role.inside : cost<BUF>(n, nn, j)) : 0.0f;
 #pragma unroll
     for (int j = 0; j < PXL; ++j) S[j] = A[j] + D[j];  // (O[r-1] + D[r]) + D[r+1]
     if (role.edge_wave) box7<true>(S, Bx, role);
@@ -196,7 +201,7 @@ struct Out {
     u32x4 lo, hi;  // 8 interpolated float pixels
 };
 
-template <bool S1, int NT>
+template <bool S1, bool PADDED, int NT>
 __device__ __forceinline__ Out row_step(float (&A)[kRegBuffers][PXL], const Parked<NT>& pk, int tid, const Line& n,
                                         const Line& nn, const LaneRole& role, float aaf)
 {
@@ -210,11 +215,11 @@ __device__ __forceinline__ Out row_step(float (&A)[kRegBuffers][PXL], const Park
     auto run = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
         if constexpr (B < kRegBuffers) {
-            buffer_step<B, S1>(A[B], vmin, rank, n, nn, role);
+            buffer_step<B, S1, PADDED>(A[B], vmin, rank, n, nn, role);
         } else {
             float t[PXL];
             pk.load_A(tid, B, t);
-            buffer_step<B, S1>(t, vmin, rank, n, nn, role);
+            buffer_step<B, S1, PADDED>(t, vmin, rank, n, nn, role);
             pk.store_A(tid, B, t);
         }
     };
@@ -274,7 +279,7 @@ __host__ __device__ constexpr int lds_bytes(int nw)
     return (4 + (kBuffers - kRegBuffers) * 2) * 16 * nw * 64 + 2 * (2 * nw - 2) * GH * kBuffers * PXL * 4;
 }
 
-template <int NW>
+template <int NW, bool PADDED>
 __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args a, float aaf)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -303,19 +308,24 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     const bool live = gl < a.nl;
     const bool real = live && !ghost;
     const int x0 = gl * PXL;
+    const int line_w = PADDED ? a.region_w : a.w;  // width of the source / destination plane
+    const bool line_live = live && x0 < line_w;
+    const bool line_real = real && x0 < line_w;
     LaneRole role;
     role.first = live && gl == 0;
     role.last = live && gl == a.nl - 1;
+    role.line_last = line_live && x0 + PXL == line_w;
+    role.inside = line_live ? 1.0f : 0.0f;
     role.first_mask = role.first ? 0xffffffffu : 0u;
     role.last_mask = role.last ? 0xffffffffu : 0u;
-    role.edge_wave = __builtin_amdgcn_readfirstlane(__any((int)(role.first || role.last)) ? 1 : 0) != 0;
+    role.edge_wave = __builtin_amdgcn_readfirstlane(__any((int)(role.first || role.last || role.line_last)) ? 1 : 0) != 0;
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(a.src + (int64_t)f * a.src_frame_stride), 0, a.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd =
         __builtin_amdgcn_make_buffer_rsrc(a.dst + (int64_t)f * a.dst_frame_stride, 0, a.dst_bytes, 0x00020000);
-    const int vload = live ? (x0 > 0 ? 4 * (x0 - 4) : 0) : kOutOfRange;
-    const int vstore = real ? 4 * x0 : kOutOfRange;
+    const int vload = line_live ? (x0 > 0 ? 4 * (x0 - 4) : 0) : kOutOfRange;
+    const int vstore = line_real ? 4 * x0 : kOutOfRange;
     const int src_step = (a.dh ? 1 : 2) * a.src_pitch;
     const int src_line = (a.dh ? 0 : a.offset) * a.src_pitch;
     const int dst_step = 2 * a.dst_pitch;
@@ -356,7 +366,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         constexpr int B = decltype(buf)::value;
         float t[PXL];
 #pragma unroll
-        for (int j = 0; j < PXL; ++j) t[j] = nr > 0 ? cost<B>(L0, L1, j) : 0.0f;
+        for (int j = 0; j < PXL; ++j) t[j] = nr > 0 ? (PADDED ? cost<B>(L0, L1, j) * role.inside : cost<B>(L0, L1, j)) : 0.0f;
         if constexpr (B < kRegBuffers) {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) A[B][j] = t[j];
@@ -419,7 +429,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
                 }
             }
         }
-        put(out_row, row_step<S1>(A, parked, tid, n, nn, role, aaf));
+        put(out_row, row_step<S1, PADDED>(A, parked, tid, n, nn, role, aaf));
         out_row += dst_step;
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c
         if (r < nr && r % K == 0) {
@@ -467,7 +477,7 @@ bool fused_f32_plane_ok(int w)
     return v3c::strips_for(w / v3c::PXL) <= f32::kMaxWaves;
 }
 
-hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes)
+hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes, int sweep_w)
 {
     v3c::Args a{};
     a.src = p.src;
@@ -476,7 +486,8 @@ hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.dst_frame_stride = p.dst_frame_stride;
     a.src_pitch = p.src_pitch;
     a.dst_pitch = p.dst_pitch;
-    a.w = p.w;
+    a.w = sweep_w > 0 ? sweep_w : p.w;  // sweep_w: the pool stride a narrower plane is swept over (PADDED)
+    a.region_w = p.w;
     a.nk = p.h_out / 2;
     a.offset = p.offset;
     a.dh = p.dh;
@@ -493,9 +504,15 @@ hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double thresh
     hipError_t e = hipSuccess;
 #define SN_LAUNCH(NW)                                                                                              \
     case NW:                                                                                                       \
-        if (lds > 64 * 1024)                                                                                       \
-            e = hipFuncSetAttribute((const void*)f32::k_fused_f32_v3<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((f32::k_fused_f32_v3<NW>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a, aaf); \
+        if (sweep_w > 0) {                                                                                         \
+            if (lds > 64 * 1024)                                                                                   \
+                e = hipFuncSetAttribute((const void*)f32::k_fused_f32_v3<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((f32::k_fused_f32_v3<NW, true>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a, aaf); \
+        } else {                                                                                                   \
+            if (lds > 64 * 1024)                                                                                   \
+                e = hipFuncSetAttribute((const void*)f32::k_fused_f32_v3<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((f32::k_fused_f32_v3<NW, false>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a, aaf); \
+        }                                                                                                          \
         break;
     switch (a.nw) {
         SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)

@@ -544,7 +544,7 @@ bool fused_padded_plane_eligible(int bytes_per_sample, int w)
     if (w % 8 != 0) return false;  // the plane must end on a lane boundary (8 columns per lane)
     if (bytes_per_sample == 1) return fused_v3_plane_ok(stride);
     if (bytes_per_sample == 2) return fused_u16_plane_ok(stride);
-    return false;
+    return fused_f32_plane_ok(stride);
 }
 
 bool fused_eligible(const sn_config& c)

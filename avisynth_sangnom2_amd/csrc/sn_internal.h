@@ -51,7 +51,7 @@ hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& 
 bool fused_eligible(const sn_config& c);
 // one plane of width w on its own (plain sweep): sample size and width within what the fused kernels take
 bool fused_plane_eligible(int bytes_per_sample, int w);
-// ... swept over its pool stride roundup(w, 32) with zero costs in the padding (fresh_pool; 8- and 16-bit)
+// ... swept over its pool stride roundup(w, 32) with zero costs in the padding (fresh_pool)
 bool fused_padded_plane_eligible(int bytes_per_sample, int w);
 bool fused_needs_pools(const sn_config& c);  // subsampled chroma: luma / chroma sweeps coupled through scratch pools
 bool fused_v2_plane_ok(int w);
@@ -79,7 +79,7 @@ hipError_t launch_fused_u8_v3(hipStream_t s, const PlaneArgs& p, double threshol
 bool fused_u16_plane_ok(int w);
 // sn_fused_f32_v3.hip: the sweep for float samples (no chroma coupling: planes of equal size only).
 bool fused_f32_plane_ok(int w);
-hipError_t launch_fused_f32_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
+hipError_t launch_fused_f32_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes, int sweep_w = 0);
 int fused_u16_waves(int sweep_w);
 int64_t fused_u16_pool_bytes(int sweep_w, int rows);
 void fused_u16_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint16_t* out);

@@ -480,7 +480,8 @@ FRESH = [
     ("Y8", 2160, 64, dict(order=2)),                  # a turned 2160p plane: stride 2176
     ("Y16", 1080, 48, {}),
     ("Y8", 100, 40, dict(aa=20)),                     # 100 % 8 != 0: pool path over a pool zeroed per frame
-    ("Y32", 720, 32, {}),                             # float: pool path
+    ("Y32", 720, 32, {}),                             # float, padded sweep
+    ("Y32", 100, 24, {}),                             # float, pool path
     ("YUV420P8", 128, 64, dict(aac=48, order=0)),     # widths that need no padding: plain sweeps
     ("YUV444P16", 200, 32, dict(aac=48, dh=True)),
     ("Y8", 7672, 16, {}),                             # stride 7680: the widest padded sweep
