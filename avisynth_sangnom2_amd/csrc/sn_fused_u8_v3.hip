@@ -830,7 +830,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.pool_frame_stride = pool->frame_stride;
     a.pool_rows = pool->pool_rows;
     a.rows_in = pool->rows_in;
-    a.rows_out = pool->pool_out ? pool->rows_out : 0;
+    a.rows_out = (pool->pool_out && !(dbg & 8)) ? pool->rows_out : 0;  // dbg 8: timing without the hand-off stores (wrong results)
     a.region_w = p.w;
     a.sweep_rows = pool->sweep_rows;
     if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);

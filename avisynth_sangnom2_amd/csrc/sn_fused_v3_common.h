@@ -38,7 +38,7 @@ struct Args {
     int32_t nw;      // physical waves
     int32_t src_bytes;  // bytes of one source plane (buffer descriptor range)
     int32_t dst_bytes;  // bytes of one destination plane
-    int32_t dbg;        // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh, 4 = refresh without its barrier (wrong results)
+    int32_t dbg;        // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh, 4 = refresh without its barrier, 8 = no hand-off stores (wrong results)
     // pool coupling for subsampled chroma (modes kLumaSpill / kChroma, see below)
     const uint8_t* pool_in;   // smoothed buffers left by the previous pass (kChroma)
     uint8_t* pool_out;        // where this pass leaves its smoothed buffers (kLumaSpill, first kChroma pass)
