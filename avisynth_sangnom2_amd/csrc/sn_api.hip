@@ -3,7 +3,7 @@
 //
 // Mirrors, on the host side, the reference's constructor and GetFrame
 // (/root/reference/src/SangNom2.cpp:275-330 and :332-397); all pixel work happens in the kernels
-// of sn_pool_kernels.hip / sn_fused_u8.hip.  There is no CPU fallback in this library.
+// of sn_pool_kernels.hip and the fused sweeps (sn_fused_*_v3.hip).  There is no CPU fallback in this library.
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -430,14 +430,11 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         a.dst += (int64_t)i * a.dst_frame_stride;
         return a;
     };
-    // SN_FUSED_VER=2 selects the previous formulation (sn_fused_u8.hip) for A/B runs
-    static const int ver = [] { const char* e = getenv("SN_FUSED_VER"); return e ? atoi(e) : 3; }();
 
     auto launch_plain_fused = [&](const sn::PlaneArgs& a, int p, int m) -> hipError_t {
         if (c->cfg.bytes_per_sample == 4) return sn::launch_fused_f32_v3(st, a, c->threshold(p), m);
         if (c->cfg.bytes_per_sample == 2) return sn::launch_fused_u16_v3(st, a, c->threshold(p), m, nullptr);
-        if ((ver == 3 || !sn::fused_v2_plane_ok(a.w)) && sn::fused_v3_plane_ok(a.w)) return sn::launch_fused_u8_v3(st, a, c->threshold(p), m, nullptr);
-        return sn::launch_fused_u8(st, a, c->threshold(p), m);
+        return sn::launch_fused_u8_v3(st, a, c->threshold(p), m, nullptr);
     };
 
     if (c->isolated) {  // every plane on its own: plain fused sweep or the pool path over the plane's own pool

@@ -1,27 +1,41 @@
-// sn_fused_u8_v3.hip -- fused 8-bit kernel, "two virtual wavefronts per wave" formulation.
+// sn_fused_u8_v3.hip -- the fused sweep for 8-bit samples: frame assembly + stage 1 + stage 2 + stage 3 of one
+// plane in ONE pass, with the nine cost buffers never leaving the CU.
 //
-// Same algorithm and the same exactness argument as sn_fused_u8.hip (read its header first):
-// one workgroup sweeps one plane top to bottom, a lane owns 8 consecutive pixels per row, the
-// nine cost buffers live in registers as A[r] = O[r-1] + D[r], ghost lanes make wave seams exact
-// with one barrier every 5 rows.
+// Reference semantics: /root/reference/src/SangNom2.cpp:74-124 (prepareBuffers_c), :126-159
+// (processBuffers_c), :161-257 (finalizePlane_c), :361-391 (GetFrame's copies).
 //
-// What is new: tools/ubench_valu.hip shows that on gfx950 only plain 32-bit add / sub / and / or /
-// lshr issue at the full VALU rate; v_add3, v_sad, v_bfe, v_lshl_or, v_min, every DPP / SDWA form
-// and every v_pk_* are half rate.  All quantities of stage 1 and 2 fit 13 bits, so every 32-bit
-// register here holds TWO pixels from two different column strips -- bits 0..15 belong to "virtual
-// wavefront" 2W (columns x), bits 16..31 to virtual wavefront 2W+1 (columns x + 480) -- and the
-// pipeline runs on plain full-rate integer ops that process both at once:
+// The sweep (the 16-bit and float files share it):
+//   * one workgroup per (frame, plane); it sweeps the plane top to bottom because stage 2 is a vertical
+//     recurrence  O[r] = box7(O[r-1] + D[r] + D[r+1]) / 16 (mod 256);
+//   * a lane owns 8 consecutive pixels of every row and keeps, per cost buffer, only A[r] = O[r-1] + D[r]:
+//     S[r] = A[r] + D[r+1],  O[r] = (box7(S[r]) >> 4) & 255,  A[r+1] = O[r] + D[r+1];
+//   * the +-3 horizontal taps of the 7-tap box come from the neighbouring lanes with DPP wave_shr:1 / wave_shl:1
+//     folded into the adds (wavefront shuffles, no LDS);
+//   * the first / last GH lanes of a wave are "ghost" lanes: they recompute everything for the columns the
+//     neighbouring wave owns.  A ghost zone of G = GH * 8 pixels stays exact in its innermost 3 pixels for
+//     floor(G / 3) rows (the missing outer neighbour corrupts 3 more pixels per row), so the waves of a workgroup
+//     only meet every K = floor(G / 3) = 5 rows: the seam lanes publish their whole A state to an LDS mailbox, one
+//     s_barrier, the ghosts reload it.  The sweep is exact across wave seams (no speculation);
+//   * image edges clamp S to the first / last column (loadPixel on the line buffer, SangNom2.cpp:144-150):
+//     per-lane selects in the two edge waves only;
+//   * stage 3's priority ladder is a minimum over keys (cost << 4) | rank: smallest cost wins, ties go to the
+//     reference's priority order; the `minBuf > aaf` test is a tenth key with cost aaf + 1 and rank 0 that selects
+//     avg(c0, n0); the winner's rank bits drive a 4-level v_bfi tree over the nine tap sums.
+//
+// "Two virtual wavefronts per wave": tools/ubench_valu.hip shows that on gfx950 only plain 32-bit add / sub / and /
+// or / lshr issue at the full VALU rate; v_add3, v_sad, v_bfe, v_lshl_or, v_min, every DPP / SDWA form and every
+// v_pk_* are half rate.  All quantities of stage 1 and 2 fit 13 bits, so every 32-bit register here holds TWO
+// pixels from two different column strips -- bits 0..15 belong to virtual wavefront W (columns x), bits 16..31 to
+// virtual wavefront W + NW (columns x + NW * 480) -- and the pipeline runs on plain full-rate integer ops that
+// process both at once:
 //     S = A + D            one v_add_u32 for two pixels (no carry can cross: sums <= 5355)
 //     box: B[j+1] = B[j] - X[j-3] + X[j+4]   plain adds; window minus a member never borrows
-//     O = (B >> 4) & 0x00ff00ff,  A' = O + D
+//     t = B & 0x0ff00ff0,  O = t >> 4,  key = t | rank,  A' = O + D
 //     SangNom value: ((4a + 5b - c + 2048) >> 3) & 0x00ff00ff   (2048 = 8 * 256 keeps it positive
 //                                                                 and does not change the result)
 //     |a - b| = max(a, b) - min(a, b) with v_pk_max_u16 / v_pk_min_u16 and one plain subtract
-// A DPP move of a packed register serves both virtual wavefronts (lane i-1 is the left neighbour
-// in both strips).  Stage 3 finds the winner with 16-bit keys (cost << 4 | rank) and
-// v_pk_min_u16, then selects the winner's tap sum with a 4-level v_bfi tree on rank-bit masks.
-//
-// Reference semantics: /root/reference/src/SangNom2.cpp:74-124, :126-159, :161-257, :361-391.
+// A DPP move of a packed register serves both virtual wavefronts (lane i-1 is the left neighbour in both strips).
+// Everything is integer; results are bit-exact to the pool path and to the opt=0 reference.
 #include <stdlib.h>
 
 #include <type_traits>

@@ -46,18 +46,16 @@ hipError_t launch_assemble(hipStream_t s, const PlaneArgs& p, int bytes, int nfr
 hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes,
                              double threshold, int nframes, int slot0);
 
-// sn_fused_u8.hip: the fused one-pass kernel (8-bit).  launch_fused_u8 also does
-// the plane's frame assembly, so launch_assemble must not be called for a plane it serves.
+// sn_fused_select.hip: which configurations the fused sweeps serve.  A fused launch also does the plane's frame
+// assembly, so launch_assemble must not be called for a plane it serves.
 bool fused_eligible(const sn_config& c);
 // one plane of width w on its own (plain sweep): sample size and width within what the fused kernels take
 bool fused_plane_eligible(int bytes_per_sample, int w);
 // ... swept over its pool stride roundup(w, 32) with zero costs in the padding (fresh_pool)
 bool fused_padded_plane_eligible(int bytes_per_sample, int w);
 bool fused_needs_pools(const sn_config& c);  // subsampled chroma: luma / chroma sweeps coupled through scratch pools
-bool fused_v2_plane_ok(int w);
 bool fused_layout_ok(const PlaneArgs& p);
-hipError_t launch_fused_u8(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
-// sn_fused_u8_v3.hip: the same sweep with two virtual wavefronts packed into every register.
+// sn_fused_u8_v3.hip: the 8-bit sweep, two virtual wavefronts packed into every register.
 bool fused_v3_plane_ok(int w);
 // Scratch-pool coupling between the luma sweep and the subsampled-chroma sweeps (sn_fused_u8_v3.hip, Mode).
 struct FusedPool {

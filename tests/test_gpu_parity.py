@@ -169,7 +169,7 @@ def test_flat_and_extreme_inputs(hip_lib):
                 assert (out[0] == src[0]).all()
 
 
-# ---- the fused 8-bit kernel (sn_fused_u8.hip) ------------------------------------------------------
+# ---- the fused sweeps (sn_fused_{u8,u16,f32}_v3.hip) -------------------------------------------------
 
 FUSED_CASES = [
     # (fmt, w, h, kw): widths chosen to hit 1, 2, 3 and 8 waves per workgroup and mid-wave right edges
