@@ -580,3 +580,27 @@ def test_anti_aliasing_idiom_on_the_device(hip_lib, fmt, w, h, kw):
         for p in range(clip.planes):
             got = dst[p][f].cpu().numpy().view(clip.dtype)
             assert same(want[f][p], got), f"frame {f} plane {p}: " + describe_diff(want[f][p], got)
+
+
+import glob as _glob
+import json as _json
+import os as _os
+
+_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _GOLDEN, ids=_os.path.basename)
+@pytest.mark.parametrize("mode", ["auto", "pool"])
+def test_committed_golden_vectors(hip_lib, path, mode):
+    """The committed input / output vectors (tests/golden/*.npz, written by make_golden.py from the oracle) through
+    the C ABI: no oracle involved on the box, frames in order on one instance."""
+    z = np.load(path)
+    meta = _json.loads(bytes(z["meta"]).decode())
+    clip = clip_format(meta["fmt"], meta["width"], meta["height"])
+    with SangNom2(clip, mode=mode, **meta["kw"]) as flt:
+        for f in range(meta["nframes"]):
+            src = [z[f"in_f{f}_p{p}"] for p in range(clip.planes)]
+            got = flt.get_frame(src, parity=(f + 1) & 1)
+            for p in range(clip.planes):
+                want = z[f"out_f{f}_p{p}"]
+                assert same(want, got[p]), f"{_os.path.basename(path)} frame {f} plane {p}: " + describe_diff(want, got[p])
