@@ -34,7 +34,37 @@ CASES = [
 ]
 
 
+# BASELINE.json's configurations at full size: too large to commit as planes, so the SHA-256 of every output plane
+# is kept; inputs come from the portable generator (avisynth_sangnom2_amd/synth.py).
+FULL_SIZE = [
+    ("1080p Y8", "Y8", 1920, 1080, dict(order=1, aa=48), "noise", 2),
+    ("2160p Y8", "Y8", 3840, 2160, dict(order=1, aa=48), "checker", 1),
+    ("2160p YUV420P8", "YUV420P8", 3840, 2160, dict(aa=48, aac=48), "noise", 1),
+    ("2160p YUV420P16", "YUV420P16", 3840, 2160, dict(aa=48, aac=48), "noise", 1),
+    ("2160p-out YUV444PS dh", "YUV444PS", 3840, 1080, dict(aa=48, aac=48, dh=True), "sine", 1),
+    ("4320p Y8", "Y8", 7680, 4320, dict(order=1, aa=48), "edges", 1),
+]
+
+
+def full_size_hashes():
+    import hashlib
+    out = []
+    for name, fmt, w, h, kw, pattern, nframes in FULL_SIZE:
+        clip = clip_format(fmt, w, h)
+        ora = Oracle(Config(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=clip.planes,
+                            subw=clip.subw, subh=clip.subh, **kw))
+        frames = []
+        for f in range(nframes):
+            res = ora.process(synth.frame(clip, pattern, seed=500 + f), parity=1)
+            frames.append([hashlib.sha256(np.ascontiguousarray(pl).tobytes()).hexdigest() for pl in res])
+        out.append(dict(name=name, fmt=fmt, width=w, height=h, kw=kw, pattern=pattern, seed0=500, sha256=frames))
+        print(name, "hashed")
+    with open(os.path.join(HERE, "full_size_sha256.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
+    full_size_hashes()
     for name, fmt, w, h, kw, pattern, nframes in CASES:
         clip = clip_format(fmt, w, h)
         ora = Oracle(Config(width=w, height=h, bytes=clip.bytes, bits=clip.bits, planes=clip.planes,

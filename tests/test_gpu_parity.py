@@ -604,3 +604,20 @@ def test_committed_golden_vectors(hip_lib, path, mode):
             for p in range(clip.planes):
                 want = z[f"out_f{f}_p{p}"]
                 assert same(want, got[p]), f"{_os.path.basename(path)} frame {f} plane {p}: " + describe_diff(want, got[p])
+
+
+with open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "full_size_sha256.json")) as _f:
+    _FULL_HASHES = _json.load(_f)
+
+
+@pytest.mark.parametrize("case", _FULL_HASHES, ids=[c["name"] for c in _FULL_HASHES])
+def test_full_size_outputs_have_the_committed_sha256(hip_lib, case):
+    """BASELINE.json's configurations at full size: every output plane hashes to the committed value
+    (tests/golden/full_size_sha256.json, from the oracle via make_golden.py; inputs from the portable generator)."""
+    import hashlib
+    clip = clip_format(case["fmt"], case["width"], case["height"])
+    with SangNom2(clip, **case["kw"]) as flt:
+        for f, want in enumerate(case["sha256"]):
+            got = flt.get_frame(synth.frame(clip, case["pattern"], seed=case["seed0"] + f), parity=1)
+            for p, digest in enumerate(want):
+                assert hashlib.sha256(np.ascontiguousarray(got[p]).tobytes()).hexdigest() == digest, f"frame {f} plane {p}"
