@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU: random formats, sizes, arguments, extension flags and frame sequences through
+the C ABI (host frames, device batches and the host ring) against oracle instances.  usage: python tools/fuzz.py [--seconds 120] [--seed 1]"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from avisynth_sangnom2_amd import ClipFormat, SangNom2, clip_format, synth  # noqa: E402
+from oracle.oracle import Config, Oracle  # noqa: E402
+
+FORMATS = ["Y8", "Y8", "Y8", "Y10", "Y16", "Y32", "YUV420P8", "YUV420P8", "YUV420P16", "YUV422P8", "YUV444P8", "YUV444PS", "YUV420PS"]
+
+
+def cfg_of(clip, **kw):
+    return Config(width=clip.width, height=clip.height, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subw, subh=clip.subh, **kw)
+
+
+def same(a, b):
+    return np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    t_end = time.time() + a.seconds
+    n = bad = 0
+    while time.time() < t_end:
+        fmt = rng.choice(FORMATS)
+        wide = rng.random() < 0.15
+        w = rng.choice([32, 64, 96, 128, 160, 256, 320, 512, 544, 640, 1024]) if not wide else rng.choice([1920, 2048, 2880, 3840, 4096, 5120, 7680])
+        if rng.random() < 0.25:
+            w = rng.choice([40, 72, 100, 200, 360, 720, 1080]) if not wide else 2160  # not a multiple of 32
+        h = 2 * rng.randint(1, 40 if not wide else 12)
+        probe = clip_format(fmt, 64, 32)
+        if probe.planes == 3:
+            w -= w % (4 if probe.subw else 1) or 0
+            if probe.subh:
+                h += (-h) % 4
+            if probe.subw and (w // 2) % 2:
+                w += 2
+        if probe.bytes > 1 and w > 3840 and rng.random() < 0.7:
+            w = 3840
+        clip = clip_format(fmt, w, h)
+        kw = dict(order=rng.randint(0, 2), aa=rng.choice([0, 1, 20, 48, 100, 128]), aac=rng.choice([0, 48, 128]),
+                  dh=rng.random() < 0.2, luma=rng.random() < 0.85, chroma=rng.random() < 0.8)
+        ext = rng.choice(["none", "none", "isolated", "fresh"])
+        nframes = rng.randint(1, 4)
+        pattern = rng.choice(["noise", "noise", "checker", "edges", "sine"])
+        frames = [synth.frame(clip, pattern, seed=rng.randint(0, 1 << 20)) for _ in range(nframes)]
+        parity = [rng.randint(0, 1) for _ in range(nframes)]
+        # expected
+        if ext == "none":
+            ora = Oracle(cfg_of(clip, **kw))
+            want = [ora.process(frames[f], parity=parity[f]) for f in range(nframes)]
+        else:
+            per_plane = {}
+            want = []
+            for f in range(nframes):
+                outs = []
+                for p in range(clip.planes):
+                    pl = frames[f][p]
+                    yclip = ClipFormat(width=pl.shape[1], height=pl.shape[0], bytes=clip.bytes, bits=clip.bits)
+                    enabled = kw["luma"] if p == 0 else kw["chroma"]
+                    mk = lambda: Oracle(cfg_of(yclip, order=kw["order"], aa=kw["aa"] if p == 0 else kw["aac"], dh=kw["dh"], luma=enabled))
+                    o = mk() if ext == "fresh" else per_plane.setdefault(p, mk())
+                    outs.append(o.process([pl], parity=parity[f])[0])
+                want.append(outs)
+        way = rng.choice(["host", "ring"])
+        try:
+            flt = SangNom2(clip, host_depth=rng.randint(1, 5), isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", **kw)
+        except Exception as e:  # a geometry the library rejects must be one it documents
+            if "exceeds the supported maximum" in str(e):
+                continue
+            raise
+        with flt:
+            got = []
+            if way == "host":
+                got = [flt.get_frame(frames[f], parity=parity[f]) for f in range(nframes)]
+            else:
+                slots = flt.host_slots()
+                inflight = []
+                for f in range(nframes):
+                    if len(inflight) == slots:
+                        got.append(flt.collect(inflight.pop(0)))
+                    inflight.append(flt.submit(frames[f], parity=parity[f]))
+                while inflight:
+                    got.append(flt.collect(inflight.pop(0)))
+        for f in range(nframes):
+            for p in range(clip.planes):
+                if not same(want[f][p], got[f][p]):
+                    bad += 1
+                    print(f"MISMATCH {fmt} {w}x{h} {kw} ext={ext} way={way} frame {f} plane {p}", flush=True)
+        n += 1
+        if n % 50 == 0:
+            print(f"{n} configurations, {bad} mismatches", flush=True)
+    print(f"fuzz: {n} configurations, {bad} mismatches (seed {a.seed})")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
