@@ -32,6 +32,7 @@ def main():
     rng = random.Random(a.seed)
     t_end = time.time() + a.seconds
     n = bad = 0
+    stats = {"fused": 0, "pool": 0, "ring": 0, "host": 0, "frames": 0, "pixels": 0}
     while time.time() < t_end:
         fmt = rng.choice(FORMATS)
         wide = rng.random() < 0.15
@@ -82,6 +83,10 @@ def main():
             raise
         with flt:
             got = []
+            fused = False
+            stats[way] += 1
+            stats["frames"] += nframes
+            stats["pixels"] += nframes * w * h
             if way == "host":
                 got = [flt.get_frame(frames[f], parity=parity[f]) for f in range(nframes)]
             else:
@@ -93,6 +98,8 @@ def main():
                     inflight.append(flt.submit(frames[f], parity=parity[f]))
                 while inflight:
                     got.append(flt.collect(inflight.pop(0)))
+            fused = flt.info().fused_frames > 0
+        stats["fused" if fused else "pool"] += 1
         for f in range(nframes):
             for p in range(clip.planes):
                 if not same(want[f][p], got[f][p]):
@@ -101,7 +108,7 @@ def main():
         n += 1
         if n % 50 == 0:
             print(f"{n} configurations, {bad} mismatches", flush=True)
-    print(f"fuzz: {n} configurations, {bad} mismatches (seed {a.seed})")
+    print(f"fuzz: {n} configurations, {bad} mismatches (seed {a.seed}); {stats}")
     sys.exit(1 if bad else 0)
 
 
