@@ -92,3 +92,18 @@ def test_staging_copy_pool_is_race_free_under_tsan():
     for workers in (0, 3, 7):
         r = subprocess.run([os.path.join(root, "host", "copier_test"), str(workers), "40"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_header_is_plain_c_and_every_entry_point_links(tmp_path):
+    """include/sangnom_hip.h compiled as C99 -pedantic; the program links against libsangnom_hip.so and runs the
+    entry points that need no GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    capi.build()
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.join(root, "avisynth_sangnom2_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_check.c"), "-o", exe, "-L", libdir, "-lsangnom_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
