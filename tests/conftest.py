@@ -14,6 +14,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def hip_lib():
-    """The in-tree libsangnom_hip.so.  GPU tests must fail loudly, not skip, if it is missing."""
+    """The in-tree libsangnom_hip.so, compiled first if a fresh checkout has not run __graft_entry__.build() yet
+    (hipcc cross-compiles without a GPU).  Tests fail loudly, never skip, if it cannot be built or loaded."""
     from avisynth_sangnom2_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        capi.build()
     return capi.load()
