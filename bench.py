@@ -144,11 +144,16 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from avisynth_sangnom2_amd import SangNom2, clip_format
+    from avisynth_sangnom2_amd import SangNom2, capi, clip_format
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not os.path.exists(capi.LIB_PATH):  # a checkout that has not run __graft_entry__.build() yet
+        if local_rank == 0:
+            capi.build()
+        while not os.path.exists(capi.LIB_PATH):
+            time.sleep(1.0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
