@@ -159,10 +159,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a box with fewer GPUs than ranks: SN_BENCH_DEVICE pins every rank to one device and
+    # SN_BENCH_BACKEND=gloo replaces RCCL for the barrier and the max-reduce (RCCL refuses two ranks on one GPU).
+    backend = os.environ.get("SN_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("SN_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     fmt, w, h, kw = WORKLOADS[args.workload]
     clip = clip_format(fmt, w, h)
@@ -184,7 +191,7 @@ def main():
     batch = args.batch or rounds * per_round
     stream = torch.cuda.Stream(dev)  # a real (non-null) HIP stream shared with the context, so that
     # torch.cuda.Event timing below sees exactly the kernels the library launches
-    flt = SangNom2(clip, device=local_rank, max_batch=batch, mode=args.mode, stream=stream.cuda_stream, **kw)
+    flt = SangNom2(clip, device=dev_index, max_batch=batch, mode=args.mode, stream=stream.cuda_stream, **kw)
     tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -224,7 +231,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
