@@ -10,7 +10,7 @@ from contextlib import nullcontext as _nullcontext
 import numpy as np
 import pytest
 
-from avisynth_sangnom2_amd import ClipFormat, SangNom2, SangNomAA, SangNomError, clip_format, synth
+from avisynth_sangnom2_amd import ClipFormat, SangNom, SangNom2, SangNomAA, SangNomError, clip_format, synth
 from oracle.oracle import Oracle
 from oracle.sangnom_numpy import NumpySangNom
 from tests.util import describe_diff, make_frames, oracle_cfg, same
@@ -621,3 +621,36 @@ def test_full_size_outputs_have_the_committed_sha256(hip_lib, case):
             got = flt.get_frame(synth.frame(clip, case["pattern"], seed=case["seed0"] + f), parity=1)
             for p, digest in enumerate(want):
                 assert hashlib.sha256(np.ascontiguousarray(got[p]).tobytes()).hexdigest() == digest, f"frame {f} plane {p}"
+
+
+def test_legacy_sangnom_wrapper_and_single_frame_device_entry(hip_lib):
+    """SangNom(clip, order, aa): order 0/1/2 = bottom/top/double-rate is remapped to SangNom2's 2/1/0
+    (src/SangNom2.cpp:441,463), aac = 0; and sn_process_device (one device-resident frame) on the context's stream."""
+    import torch
+    clip = clip_format("YUV420P8", 128, 64)
+    frames = make_frames(clip, "noise", 2, seed0=5)
+    for legacy_order, order in ((0, 2), (1, 1), (2, 0)):
+        ora = Oracle(oracle_cfg(clip, order=order, aa=30, aac=0))
+        with SangNom(clip, order=legacy_order, aa=30) as flt:
+            assert flt.stream_handle() not in (None, 0)
+            for f, fr in enumerate(frames):
+                want = ora.process(fr, parity=f)
+                got = flt.get_frame(fr, parity=f)
+                dev = torch.device("cuda:0")
+                src = [torch.from_numpy(pl).to(dev) for pl in fr]
+                dst = [torch.zeros_like(s) for s in src]
+                torch.cuda.synchronize()
+                for p in range(3):
+                    assert same(want[p], got[p]), f"legacy order {legacy_order} frame {f} plane {p}"
+    with pytest.raises(SangNomError, match="order must be between 0..2"):
+        SangNom(clip, order=3)
+    # the single-frame device entry point: same frame, same result (history-free clip)
+    with SangNom2(clip, aa=30) as flt:
+        want = Oracle(oracle_cfg(clip, aa=30)).process(frames[0])
+        src = [torch.from_numpy(pl).to(dev) for pl in frames[0]]
+        dst = [torch.zeros_like(s) for s in src]
+        torch.cuda.synchronize()
+        flt.get_frame_device(src, dst)
+        flt.synchronize()
+        for p in range(3):
+            assert same(want[p], dst[p].cpu().numpy()), f"device frame plane {p}"
