@@ -328,6 +328,13 @@ static int create_impl(const sn_config* cfg, Context* c)
         return (int)(n < 1 ? 1 : n < want ? n : want);
     };
     c->slots = c->history_free ? fit(c->pool.slot_bytes) : 1;
+    if (c->use_fused) {
+        // the fused sweeps serve this configuration: the pool path only takes the launches that are too small to
+        // be worth a sweep (prefer_pool below), so a few slots are enough
+        const int64_t cap = (4ll << 30) / c->pool.slot_bytes;
+        const int small = (int)(cap < 1 ? 1 : cap > 64 ? 64 : cap);
+        if (c->slots > small) c->slots = small;
+    }
     if (!c->use_fused) {
         for (int p = 0; p < (c->isolated ? c->nplanes() : 1); ++p) {
             if (c->isolated && (c->plane_fused[p] || !(cfg->dh || c->process[p]))) continue;
@@ -400,6 +407,32 @@ static int check_planes(Context* c, const void* const src[3], const int32_t sp[3
     return SN_OK;
 }
 
+// A fused sweep walks a plane row by row: its time hardly depends on how many frames the launch carries (up to a
+// round of resident workgroups) but it never takes less than rows x 3.5-5.7 us -- 3.8 ms for one 2160p 8-bit
+// plane.  The pool path spreads ONE frame over the whole chip (1.0 ms for that plane) and costs about 15-33 ps per
+// pool element and frame beyond that.  Both are exact, so in SN_MODE_AUTO small launches -- a synchronous GetFrame,
+// a short look-ahead -- take the pool path (measured crossover at 2160p: about 48 frames for 8-bit Y, 42 for 16-bit
+// and float, 70 for 8-bit 4:2:0; the estimate below switches a little earlier).
+static bool prefer_pool(const Context* c, int n, int slot0)
+{
+    if (c->cfg.mode != SN_MODE_AUTO || !c->history_free || slot0 + n > c->slots) return false;
+    const int B = c->cfg.bytes_per_sample;
+    const double t_row = B == 1 ? 3.5e-6 : B == 2 ? 4.05e-6 : 5.7e-6;     // fused sweep, per row
+    const double per_elem = B == 1 ? 14.7e-12 : B == 2 ? 20e-12 : 32.5e-12;  // pool path, per pool element and frame
+    double fused = 0, pool = 0;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        if (!(c->cfg.dh || c->process[p])) continue;
+        const bool own = c->isolated;  // own pool geometry per plane, else the luma-sized shared pool
+        const int stride = own ? c->plane_pool[p].stride_e : c->stride_e;
+        const int bh = own ? c->plane_pool[p].bh : c->bh;
+        const int rows = (c->fused420 ? c->out_height : c->plane_h_out(p)) / 2;
+        fused += rows * t_row;
+        const int cols_per_thread = (stride + 1023) / 1024;
+        pool += bh * (0.35e-6 + 0.15e-6 * cols_per_thread) + 60e-6 + (double)n * stride * bh * per_elem;
+    }
+    return pool < 0.8 * fused;
+}
+
 // Runs frames [f0, f0 + n) of a strided batch with one common field offset.
 // `st` is the stream to launch on and `slot0` the first scratch slot the frames may use (the batch entry points
 // pass the context's stream and slot 0, the host ring one frame on its slot's stream and scratch).
@@ -423,8 +456,10 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         a.offset = offset;
         a.dh = c->cfg.dh;
         a.enabled = (c->cfg.dh || c->process[p]) ? 1 : 0;
-        fused[p] = a.enabled && c->use_fused && sn::fused_layout_ok(a);
+        fused[p] = a.enabled && (c->isolated ? c->plane_fused[p] : c->use_fused) && sn::fused_layout_ok(a);
     }
+    if (prefer_pool(c, n, slot0))
+        for (int p = 0; p < 3; ++p) fused[p] = false;
     auto frames_from = [](sn::PlaneArgs a, int i) {
         a.src += (int64_t)i * a.src_frame_stride;
         a.dst += (int64_t)i * a.dst_frame_stride;
@@ -441,7 +476,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         bool counted = false;
         for (int p = 0; p < c->nplanes(); ++p) {
             const sn::PlaneArgs& a = pa[p];
-            if (a.enabled && c->plane_fused[p] && sn::fused_layout_ok(a)) {
+            if (fused[p] && c->plane_fused[p]) {
                 if (c->plane_padded[p]) {
                     // the sweep covers the whole pool stride: costs are zero outside the plane, the box filter clamps
                     // at the end of the stride (SangNom2.cpp:144-150)
