@@ -416,6 +416,8 @@ static int check_planes(Context* c, const void* const src[3], const int32_t sp[3
 static bool prefer_pool(const Context* c, int n, int slot0)
 {
     if (c->cfg.mode != SN_MODE_AUTO || !c->history_free || slot0 + n > c->slots) return false;
+    if (const char* e = getenv("SN_PREFER_POOL"))  // 0: always sweep (the tests use it to reach the sweeps with small clips)
+        if (atoi(e) == 0) return false;
     const int B = c->cfg.bytes_per_sample;
     const double t_row = B == 1 ? 3.5e-6 : B == 2 ? 4.05e-6 : 5.7e-6;     // fused sweep, per row
     const double per_elem = B == 1 ? 14.7e-12 : B == 2 ? 20e-12 : 32.5e-12;  // pool path, per pool element and frame

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "small_launch_policy: keeps auto mode's pool path for small launches switched on")
 
 
 @pytest.fixture(scope="session")
@@ -20,3 +21,10 @@ def hip_lib():
     if not os.path.exists(capi.LIB_PATH):
         capi.build()
     return capi.load()
+
+
+@pytest.fixture
+def sweeps_always(monkeypatch):
+    """In auto mode the library gives launches of a few frames to the pool path (both paths are exact); parity tests
+    that mean to exercise the fused sweeps with small clips switch that off."""
+    monkeypatch.setenv("SN_PREFER_POOL", "0")

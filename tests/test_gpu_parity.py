@@ -15,6 +15,14 @@ from oracle.oracle import Oracle
 from oracle.sangnom_numpy import NumpySangNom
 from tests.util import describe_diff, make_frames, oracle_cfg, same
 
+
+@pytest.fixture(autouse=True)
+def _sweeps_unless_asked_otherwise(request, monkeypatch):
+    """Auto mode hands launches of a few frames to the pool path; these tests want the fused sweeps wherever a
+    configuration is eligible, so that policy is off here except in the tests that are about it."""
+    if "small_launch_policy" not in request.keywords:
+        monkeypatch.setenv("SN_PREFER_POOL", "0")
+
 pytestmark = pytest.mark.gpu
 
 PATTERNS = ("noise", "checker", "sine", "edges")
@@ -654,3 +662,35 @@ def test_legacy_sangnom_wrapper_and_single_frame_device_entry(hip_lib):
         flt.synchronize()
         for p in range(3):
             assert same(want[p], dst[p].cpu().numpy()), f"device frame plane {p}"
+
+
+@pytest.mark.small_launch_policy
+@pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 3840, 2160, {}), ("YUV420P8", 1920, 1080, dict(aac=48)), ("Y16", 1920, 1080, {}),
+                                        ("YUV420P8", 720, 480, dict(aac=48, fresh_pool=True))])
+def test_small_launches_take_the_pool_path_and_large_ones_the_sweeps(hip_lib, fmt, w, h, kw):
+    """SN_MODE_AUTO: one frame goes through the pool kernels, a launch of a whole round of workgroups through the
+    fused sweeps; same bytes either way."""
+    import torch
+    clip = clip_format(fmt, w, h)
+    dev = torch.device("cuda:0")
+    N = 1024 if w <= 720 else 256
+    tdt = {1: torch.uint8, 2: torch.int16}[clip.bytes]
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    src = []
+    for p in range(clip.planes):
+        hp, wp = h >> (clip.subh if p else 0), w >> (clip.subw if p else 0)
+        hi = 256 if clip.bytes == 1 else 1 << clip.bits
+        src.append(torch.randint(0, hi, (N, hp, wp), device=dev, generator=g, dtype=torch.int32).to(tdt))
+    with SangNom2(clip, max_batch=N, **kw) as flt:
+        one = [torch.zeros_like(s[:1]) for s in src]
+        torch.cuda.synchronize()
+        flt.process_batch([s[:1] for s in src], one)
+        flt.synchronize()
+        assert flt.info().fused_frames == 0, "a single frame should have taken the pool path"
+        out = [torch.zeros_like(s) for s in src]
+        flt.process_batch(src, out)
+        flt.synchronize()
+        assert flt.info().fused_frames == N, "a full launch should have taken the fused sweeps"
+        for p in range(clip.planes):
+            assert torch.equal(one[p][0], out[p][0]), f"plane {p}: the two paths disagree"

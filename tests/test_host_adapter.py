@@ -33,7 +33,8 @@ def _run(tmp_path, clip, kw, frames, parities, extra=()):
             f.write(struct.pack("<i", par))
             for pl in fr:
                 f.write(np.ascontiguousarray(pl).tobytes())
-    r = subprocess.run([BIN, fin, fout, *[str(x) for x in extra]], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, SN_PREFER_POOL="0")  # small clips: reach the fused sweeps, not auto mode's pool path
+    r = subprocess.run([BIN, fin, fout, *[str(x) for x in extra]], capture_output=True, text=True, timeout=300, env=env)
     return r, fout
 
 

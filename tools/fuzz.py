@@ -75,6 +75,7 @@ def main():
                     outs.append(o.process([pl], parity=parity[f])[0])
                 want.append(outs)
         way = rng.choice(["host", "ring"])
+        os.environ["SN_PREFER_POOL"] = rng.choice(["0", "0", "1"])  # mostly the sweeps, sometimes auto mode's small-launch pool path
         try:
             flt = SangNom2(clip, host_depth=rng.randint(1, 5), isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", **kw)
         except Exception as e:  # a geometry the library rejects must be one it documents
