@@ -202,14 +202,15 @@ void sn_destroy(sn_context* h)
     Context* c = reinterpret_cast<Context*>(h);
     if (!c) return;
     (void)hipSetDevice(c->device);
+    // every stream that may still run kernels on this context's scratch drains first; only then is memory freed
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& g : c->ring)
+        if (g.stream) (void)hipStreamSynchronize(g.stream);
     if (c->pool.base) (void)hipFree(c->pool.base);
     for (int p = 0; p < 3; ++p)
         if (c->plane_pool[p].base) (void)hipFree(c->plane_pool[p].base);
     for (int i = 0; i < 2; ++i)
         if (c->fpool[i]) (void)hipFree(c->fpool[i]);
-    for (auto& g : c->ring)
-        if (g.stream) (void)hipStreamSynchronize(g.stream);
     delete c->copier;
     for (int p = 0; p < 3; ++p) {
         if (c->ring_pin_in[p]) (void)hipHostFree(c->ring_pin_in[p]);

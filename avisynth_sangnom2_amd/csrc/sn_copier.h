@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -38,7 +39,11 @@ public:
     }
     void run(const Job* jobs, int njobs)
     {
-        bands_.clear();
+        // Every call hands out its OWN immutable batch (bands + counters).  A worker that wakes late still holds
+        // the batch of the call it was woken for: its counters are exhausted, so it leaves without touching the
+        // bands of a later call (one shared set of counters let such a worker take a band index of the previous
+        // call and apply it to the next one: a band copied twice, another one not yet copied when run() returned).
+        auto batch = std::make_shared<Batch>();
         for (int j = 0; j < njobs; ++j) {
             const Job& b = jobs[j];
             const int step = b.row_bytes > 0 ? (kBandBytes + b.row_bytes - 1) / b.row_bytes : b.rows;
@@ -47,28 +52,31 @@ public:
                 band.dst += (size_t)y * b.dpitch;
                 band.src += (size_t)y * b.spitch;
                 band.rows = b.rows - y < step ? b.rows - y : step;
-                bands_.push_back(band);
+                batch->bands.push_back(band);
             }
         }
-        if (threads_.empty() || bands_.size() < 2) {
-            for (const Job& b : bands_) copy(b);
+        if (threads_.empty() || batch->bands.size() < 2) {
+            for (const Job& b : batch->bands) copy(b);
             return;
         }
-        {   // bands_ is complete before the counters are reset: a worker that sees the reset sees the bands
+        batch->left.store((int)batch->bands.size());
+        {
             std::lock_guard<std::mutex> lk(m_);
-            nbands_.store((int)bands_.size());
-            left_.store((int)bands_.size());
-            next_.store(0);
+            current_ = batch;
             ++epoch_;
         }
         cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(m_);  // every band copied and no worker still inside work()
-        done_.wait(lk, [this] { return left_.load() == 0 && busy_ == 0; });
+        work(*batch);
+        std::unique_lock<std::mutex> lk(m_);  // every band of THIS batch copied
+        done_.wait(lk, [&] { return batch->left.load() == 0; });
     }
 
 private:
     static constexpr int kBandBytes = 512 * 1024;
+    struct Batch {
+        std::vector<Job> bands;
+        std::atomic<int> next{0}, left{0};
+    };
     static void copy(const Job& b)
     {
         if (b.dpitch == b.spitch && b.dpitch == b.row_bytes) {
@@ -77,12 +85,16 @@ private:
         }
         for (int y = 0; y < b.rows; ++y) memcpy(b.dst + (size_t)y * b.dpitch, b.src + (size_t)y * b.spitch, b.row_bytes);
     }
-    void work()
+    // returns true if this thread copied the batch's last band
+    static bool work(Batch& b)
     {
-        for (int i = next_.fetch_add(1); i < nbands_.load(); i = next_.fetch_add(1)) {
-            copy(bands_[i]);
-            left_.fetch_sub(1);
+        bool last = false;
+        const int n = (int)b.bands.size();
+        for (int i = b.next.fetch_add(1); i < n; i = b.next.fetch_add(1)) {
+            copy(b.bands[i]);
+            last = b.left.fetch_sub(1) == 1;
         }
+        return last;
     }
     void loop()
     {
@@ -92,21 +104,18 @@ private:
             cv_.wait(lk, [&] { return quit_ || epoch_ != seen; });
             if (quit_) return;
             seen = epoch_;
-            ++busy_;
+            std::shared_ptr<Batch> batch = current_;
             lk.unlock();
-            work();
+            const bool last = work(*batch);
             lk.lock();
-            --busy_;
-            done_.notify_all();
+            if (last) done_.notify_all();  // under m_: run() is either before its predicate check or waiting
         }
     }
     std::vector<std::thread> threads_;
-    std::vector<Job> bands_;
     std::mutex m_;
     std::condition_variable cv_, done_;
-    std::atomic<int> next_{0}, left_{0}, nbands_{0};
+    std::shared_ptr<Batch> current_;  // guarded by m_
     uint64_t epoch_ = 0;
-    int busy_ = 0;  // workers inside work(), guarded by m_
     bool quit_ = false;
 };
 

@@ -157,10 +157,10 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
     const int f = blockIdx.y;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     T* buf = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
-    const int x0 = threadIdx.x * NC;
-    // the workgroup has ceil(se / NC) threads rounded up to whole waves; the idle lanes of the last wave leave (their
-    // wave still meets every barrier)
-    if (x0 >= se) return;
+    // the workgroup has ceil(se / NC) threads rounded up to whole waves; the idle lanes of the last wave compute on
+    // column 0's data and store nothing, so every thread reaches every barrier
+    const bool active = (int)threadIdx.x * NC < se;
+    const int x0 = active ? threadIdx.x * NC : 0;
 
     auto load = [&](int row, W (&out)[NC]) {
         const Vec t = *reinterpret_cast<const Vec*>(buf + (size_t)row * se + x0);
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             X[3 + k] = P::sum3(prev[k], cur[k], nxt[k]);
-            line[x0 + k] = X[3 + k];
+            if (active) line[x0 + k] = X[3 + k];
         }
         __syncthreads();
 #pragma unroll
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
             cur[k] = nxt[k];
             nxt[k] = pre[k];
         }
-        *reinterpret_cast<Vec*>(buf + (size_t)r * se + x0) = o;
+        if (active) *reinterpret_cast<Vec*>(buf + (size_t)r * se + x0) = o;
     }
 }
 
@@ -321,14 +321,10 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
     if (pool.bh > 1) {
         // columns per thread: what 1024 threads need, and 4 for every pool of 1024 columns or more (vector accesses,
         // fewer LDS round trips); narrower pools do best with one column per thread
-        static const int forced = [] { const char* e = getenv("SN_SMOOTH_NC"); return e ? atoi(e) : 0; }();
         int nc = (pool.stride_e + kSmoothThreads - 1) / kSmoothThreads;
         nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
         if (nc < 4 && pool.stride_e >= 1024) nc = 4;
-        if (forced && forced >= nc) nc = forced;
-        static const int thr_floor = [] { const char* e = getenv("SN_SMOOTH_THREADS"); return e ? atoi(e) : 0; }();
-        int threads = ((pool.stride_e / nc) + 63) / 64 * 64;
-        if (threads < thr_floor) threads = thr_floor;
+        const int threads = ((pool.stride_e / nc) + 63) / 64 * 64;
         const size_t lds = (size_t)2 * pool.stride_e * sizeof(W);
         dim3 grid(kBuffers, nframes), block(threads);
         hipError_t e = hipSuccess;

@@ -8,6 +8,11 @@ quoted on: 2160p Y8, order=1, aa=48.  One process per GPU; frames shard across r
 data-path collective (weak scaling: every rank processes its own batch); torch.distributed (RCCL)
 is used only for the start/stop barrier and the max-over-ranks of the elapsed time.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` as a child (one rank per GPU),
+relays rank 0's JSON line and exits with the child's code.  Under a launcher (WORLD_SIZE set) `--gpus` must
+agree with it.  `n_gpus` in the JSON line is the number of ranks that actually joined the process group.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -56,25 +61,36 @@ def algorithmic_bytes_per_frame(clip, flt, kw) -> int:
     return total
 
 
-def recorded_traffic(workload: str, batch: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.csv, made by
-    tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950 coalesced reads).  Only valid for the workload and
-    batch the passes were run on (profiles/r1_bench.json); None otherwise -- the counters cannot be read
-    from inside this process."""
-    import csv
-    import json
+PROFILE_TAG = "r2"  # profiles/<tag>_counters.json is what recorded_counters() reads
+
+
+def recorded_counters(workload: str, batch: int):
+    """Per-launch PMC figures of this workload from the committed rocprofv3 passes: profiles/r2_counters.json
+    (written by tools/pmc_summary.py --json from the passes of tools/profile_round.sh / profile_workloads.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950 coalesced reads; SQ counters in a pass of their own).  The counters cannot be read from inside
+    this process, so these are RECORDED values: valid only for the workload and batch they were collected on
+    (None otherwise), and the bench line says so in `traffic_source`."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters.json")
     try:
-        ref = json.loads(open(os.path.join(ROOT, "profiles", "r1_bench.json")).read().strip().splitlines()[-1])
-        if not ref["config"]["workload"].startswith(workload + " ") or ref["config"]["frames_per_step_per_gpu"] != batch:
+        rec = json.load(open(path)).get(workload)
+        if not rec or rec.get("frames_per_launch") != batch:
             return None
-        vals = {}
-        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.csv"))):
-            if row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals[row["counter"]] = float(row["sum_over_dims"])  # last dispatch wins
-        return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-    except (OSError, KeyError, ValueError, IndexError):
+        rec = dict(rec)
+        rec["source"] = f"recorded:profiles/{PROFILE_TAG}_counters.json"
+        return rec
+    except (OSError, ValueError):
         return None
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
@@ -126,8 +142,26 @@ def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
     dt = time.perf_counter() - t0
     frames = cores * per_thread
     return {"value": round(frames * w * out_h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model(),
             "sample": f"{label}: {frames} frames of {fmt} {w}x{h} uniform noise, {cores} threads x {per_thread} frames, "
-                      f"one filter instance per thread ({dt:.1f} s; single-thread {one * 1e3:.0f} ms/frame)"}
+                      f"one filter instance per thread ({dt:.1f} s; single-thread {one * 1e3:.0f} ms/frame) on "
+                      f"{os.cpu_count()} logical CPUs of {cpu_model()}"}
+
+
+def spawn_ranks(args) -> int:
+    """`--gpus N` without a launcher: run the N ranks as children of this process, which has not touched the
+    GPU (no torch.cuda call, no HIP library loaded) and never will -- a process that has initialised the GPU
+    must not exec or fork workers.  Rank 0 prints the JSON line; it is passed through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -140,6 +174,12 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "pool", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks")
 
     import torch
     import torch.distributed as dist
@@ -240,13 +280,30 @@ def main():
     launch_ms = sum(dev_ms) / len(dev_ms)
     info = flt.info()
 
+    joined = dist.get_world_size() if world > 1 else 1  # ranks that really took part
     if rank == 0:
-        frames_total = batch * args.steps * world
+        frames_total = batch * args.steps * joined
         mpix = frames_total * w * out_h / elapsed / 1e6
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        rec = recorded_counters(args.workload, batch) or {}
+        traffic = rec.get("hbm_bytes_per_launch")
+        # What limits the sweep is the vector ALU's issue rate, not HBM: the HBM figures below are
+        # the roofline north_star asks for, `valu` says how the limiting unit is used.  Instruction counts are a
+        # property of the build (recorded PMC pass), the time is this run's.
+        valu = None
+        if rec.get("valu_insts_per_launch"):
+            simds, clock_hz = 256 * 4, 2.4e9
+            insts = rec["valu_insts_per_launch"]
+            valu = {"wave_insts_per_launch": insts,
+                    "lane_ops_per_output_pixel": round(insts * 64 / (batch * w * out_h), 2),
+                    "cycles_per_inst_per_simd": round(launch_ms * 1e-3 * clock_hz * simds / insts, 3),
+                    "clock_ghz_assumed": 2.4,
+                    "valu_issue_share_of_wave_life": rec.get("valu_active_frac"),
+                    "stall_share_of_wave_life": rec.get("stall_frac"),
+                    "source": rec["source"]}
         out = {
             "metric": "Mpixels/s", "value": round(mpix, 1), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": {1: "u8", 2: "u16", 4: "f32"}[clip.bytes],
             "data": "synthetic",
@@ -255,10 +312,12 @@ def main():
                        "frames_per_step_per_gpu": batch, "frame": f"{w}x{out_h} {fmt}",
                        "path": "fused" if info.fused_frames > 0 else "pool", "sharding": "frames, no collective"},
             "frames_per_s": round(frames_total / elapsed, 1),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(args.workload, batch),
+            "roofline": {"bound": "valu-issue", "roofline_reported": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": rec.get("source") if traffic else None,
                          "kernel_ms_per_launch": round(launch_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes, "valu": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fmt, w, h, kw)

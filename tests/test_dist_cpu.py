@@ -75,3 +75,45 @@ def test_two_ranks_shard_a_stream():
     ora = Oracle(oracle_cfg(clip))
     want = {f: int(ora.process(synth.frame(clip, "noise", seed=f))[0].astype(np.uint64).sum()) for f in range(n_frames)}
     assert merged == want
+
+
+# ---- bench.py --gpus N: the launcher logic (no GPU involved) -----------------------------------------------
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sn_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """`bench.py --gpus N` without a launcher must start N ranks (torch.distributed.run, 127.0.0.1 rendezvous)
+    from a process that has not touched the GPU, and pass its own arguments on unchanged."""
+    import subprocess
+    import sys
+    bench = _bench_module()
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    (cmd, env), = calls
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch.cuda" not in sys.modules or not sys.modules["torch"].cuda.is_initialized()
+
+
+def test_bench_gpus_flag_must_agree_with_the_launcher(monkeypatch):
+    import sys
+    bench = _bench_module()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)

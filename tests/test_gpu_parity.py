@@ -694,3 +694,57 @@ def test_small_launches_take_the_pool_path_and_large_ones_the_sweeps(hip_lib, fm
         assert flt.info().fused_frames == N, "a full launch should have taken the fused sweeps"
         for p in range(clip.planes):
             assert torch.equal(one[p][0], out[p][0]), f"plane {p}: the two paths disagree"
+
+
+# ---- one frame stream over G replicas (MT_MULTI_INSTANCE, SangNom2.h:63-66) ---------------
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("mode", ["round_robin", "block"])
+@pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 512, 96, {}), ("YUV420P8", 256, 64, dict(aac=48))], ids=["Y8", "YUV420P8"])
+def test_a_stream_sharded_over_logical_ranks_equals_one_context(hip_lib, world, mode, fmt, w, h, kw):
+    """G logical ranks mapped to one device, each with its own context (as bench.py --gpus G gives every GPU its
+    own): rank r sweeps the frames shard.frames_for_rank hands it; reassembled in stream order the outputs are
+    byte-for-byte what ONE context produces for the whole stream, and one frame per rank is checked against the oracle."""
+    import torch
+    from avisynth_sangnom2_amd import shard
+    clip = clip_format(fmt, w, h)
+    n_frames = 67  # not a multiple of the world size
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(5150)
+    shapes = [(h >> (clip.subh if p else 0), w >> (clip.subw if p else 0)) for p in range(clip.planes)]
+    src = [torch.randint(0, 256, (n_frames,) + sh, device=dev, generator=g, dtype=torch.uint8) for sh in shapes]
+    parity = [(f * 7) & 1 for f in range(n_frames)]
+    kw = dict(kw, order=0)  # order 0: the field follows the frame's parity, so a shard must carry its own parities
+    torch.cuda.synchronize()
+    with SangNom2(clip, max_batch=n_frames, mode="fused", **kw) as one:
+        want = [torch.zeros_like(s) for s in src]
+        one.process_batch(src, want, parity)
+        one.synchronize()
+    got = [torch.zeros_like(s) for s in src]
+    ranks = [SangNom2(clip, max_batch=n_frames, mode="fused", **kw) for _ in range(world)]
+    try:
+        covered = []
+        for r, flt in enumerate(ranks):
+            mine = shard.frames_for_rank(n_frames, r, world, mode)
+            covered += mine
+            idx = torch.tensor(mine, device=dev, dtype=torch.long)
+            s_r = [s.index_select(0, idx) for s in src]       # the rank's private batch
+            d_r = [torch.zeros_like(x) for x in s_r]
+            torch.cuda.synchronize()
+            flt.process_batch(s_r, d_r, [parity[f] for f in mine])
+            flt.synchronize()
+            assert flt.info().fused_frames == len(mine)
+            for p in range(clip.planes):
+                got[p].index_copy_(0, idx, d_r[p])
+        assert sorted(covered) == list(range(n_frames))
+        torch.cuda.synchronize()
+        for p in range(clip.planes):
+            assert torch.equal(got[p], want[p]), f"plane {p}: sharded stream differs from the single context"
+        for r in range(world):
+            f = shard.frames_for_rank(n_frames, r, world, mode)[-1]
+            ref = Oracle(oracle_cfg(clip, **kw)).process([s[f].cpu().numpy() for s in src], parity=parity[f])
+            for p in range(clip.planes):
+                assert same(ref[p], got[p][f].cpu().numpy())
+    finally:
+        for flt in ranks:
+            flt.close()

@@ -1,187 +1,244 @@
-// ubench_valu.hip -- issue-rate microbenchmark for the integer VALU instructions the fused
-// SangNom2 kernel is made of (gfx950).  For each instruction: cycles per wave-instruction per
-// SIMD at 1, 2 and 4 waves per SIMD (independent register chains, no memory traffic).
+// ubench_valu.hip -- VALU issue microbenchmark for gfx950 (round 2 rewrite).
+//
+// Round 1's version put every measured instruction into its own `asm volatile`, and hipcc pads an `s_nop 0`
+// after each of those: the 1- and 2-wave columns then measured instruction + nop pairs.  Here the whole unrolled
+// body (128 instructions) is ONE asm block with hard-coded registers, so nothing can be inserted between the
+// measured instructions (check: `hipcc -S --cuda-device-only` shows no s_nop inside the loops), and the time
+// comes from s_memtime inside the kernel (shader cycles, independent of the clock the chip holds).
+//
+// For each instruction form:
+//   ind   eight independent accumulator chains (a result is consumed eight instructions later)
+//   dep   ONE dependent chain (every instruction consumes the previous result)
+// at 1, 2, 3, 4 and 8 waves per SIMD.  Output: cycles per wave-instruction as the SIMD sees it
+// (= wave cycles / instructions / waves per SIMD).
+// Also: mixes of fast and slow forms shaped like the fused sweep's row body.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o /tmp/ubench_valu && /tmp/ubench_valu
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
 
-#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#include <algorithm>
+#include <string>
+#include <vector>
 
-#define DEFK(NAME, ASM)                                                                        \
-    __global__ void __launch_bounds__(1024) k_##NAME(unsigned* out, int iters)                 \
-    {                                                                                          \
-        unsigned r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, \
-                 r6 = r0 + 6, r7 = r0 + 7, a = r0 * 3 + 1, b = r0 * 5 + 2;                     \
-        asm volatile("s_mov_b64 s[10:11], 0x5555\n\ts_mov_b64 vcc, 0x3333" ::: "s10", "s11", "s12", "vcc");           \
-        for (int i = 0; i < iters; ++i) {                                                      \
-            _Pragma("unroll") for (int u = 0; u < 8; ++u)                                      \
-            {                                                                                  \
-                asm volatile(ASM(0) : "+v"(r0) : "v"(a), "v"(b) : "vcc");                              \
-                asm volatile(ASM(1) : "+v"(r1) : "v"(a), "v"(b) : "vcc");                              \
-                asm volatile(ASM(2) : "+v"(r2) : "v"(a), "v"(b) : "vcc");                              \
-                asm volatile(ASM(3) : "+v"(r3) : "v"(a), "v"(b) : "vcc");                              \
-                asm volatile(ASM(4) : "+v"(r4) : "v"(a), "v"(b) : "vcc");                              \
-                asm volatile(ASM(5) : "+v"(r5) : "v"(a), "v"(b) : "vcc");                              \
-                asm volatile(ASM(6) : "+v"(r6) : "v"(a), "v"(b) : "vcc");                              \
-                asm volatile(ASM(7) : "+v"(r7) : "v"(a), "v"(b) : "vcc");                              \
-            }                                                                                  \
-        }                                                                                      \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;   \
+// v[10..17] accumulators, v18/v19 operands
+#define X8(A, B, C, D, E, F, G, H) A "\n\t" B "\n\t" C "\n\t" D "\n\t" E "\n\t" F "\n\t" G "\n\t" H "\n\t"
+#define IND8(OP) X8(OP(10), OP(11), OP(12), OP(13), OP(14), OP(15), OP(16), OP(17))
+#define DEP8(OP) X8(OP(10), OP(10), OP(10), OP(10), OP(10), OP(10), OP(10), OP(10))
+#define DEP2_8(OP) X8(OP(10), OP(11), OP(10), OP(11), OP(10), OP(11), OP(10), OP(11))
+#define R16(B) B B B B B B B B B B B B B B B B
+
+#define CLOB "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "vcc", "s10", "s11"
+
+#define DEFK(NAME, BODY128)                                                                                  \
+    __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long* out, int iters)                     \
+    {                                                                                                        \
+        asm volatile("v_mov_b32 v10, %0\n\tv_add_u32 v11, 1, %0\n\tv_add_u32 v12, 2, %0\n\tv_add_u32 v13, 3, %0\n\t" \
+                     "v_add_u32 v14, 4, %0\n\tv_add_u32 v15, 5, %0\n\tv_add_u32 v16, 6, %0\n\tv_add_u32 v17, 7, %0\n\t" \
+                     "v_mul_u32_u24 v18, 3, %0\n\tv_mul_u32_u24 v19, 5, %0\n\ts_mov_b64 s[10:11], 0x5555"       \
+                     :: "v"(threadIdx.x) : CLOB);                                                            \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                          \
+        for (int i = 0; i < iters; ++i) asm volatile(BODY128 ::: CLOB);                                      \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                          \
+        unsigned r;                                                                                          \
+        asm volatile("v_xor_b32 %0, v10, v11\n\tv_xor_b32 %0, %0, v12\n\tv_xor_b32 %0, %0, v13\n\tv_xor_b32 %0, %0, v14\n\t" \
+                     "v_xor_b32 %0, %0, v15\n\tv_xor_b32 %0, %0, v16\n\tv_xor_b32 %0, %0, v17" : "=v"(r) :: CLOB); \
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x;                                               \
+        out[gid] = ((t1 - t0) << 8) | (r & 0xff);                                                            \
     }
 
-#define A_ADD(n) "v_add_u32 %0, %0, %1"
-#define A_ADD3(n) "v_add3_u32 %0, %0, %1, %2"
-#define A_SAD(n) "v_sad_u16 %0, %0, %1, %2"
-#define A_BFE(n) "v_bfe_u32 %0, %0, 3, 8"
-#define A_LSHLOR(n) "v_lshl_or_b32 %0, %0, 16, %1"
-#define A_MIN(n) "v_min_u32 %0, %0, %1"
-#define A_MIN3(n) "v_min3_u32 %0, %0, %1, %2"
-#define A_ADDDPP(n) "v_add_u32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-#define A_ADDDPPROW(n) "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-#define A_MOVDPP(n) "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-#define A_ADDSDWA(n) "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-#define A_PKADD(n) "v_pk_add_u16 %0, %0, %1"
-#define A_PKSUB(n) "v_pk_sub_i16 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]"
-#define A_PKMAX(n) "v_pk_max_i16 %0, %0, %1"
-#define A_CNDMASK(n) "v_cndmask_b32 %0, %0, %1, vcc"
-#define A_MUL24(n) "v_mul_u32_u24 %0, %0, %1"
-#define A_MAD24(n) "v_mad_u32_u24 %0, %0, %1, %2"
-#define A_AND(n) "v_and_b32 %0, %0, %1"
-#define A_ANDOR(n) "v_and_or_b32 %0, %0, %1, %2"
-#define A_PERM(n) "v_perm_b32 %0, %0, %1, %2"
-#define A_ALIGNBYTE(n) "v_alignbyte_b32 %0, %0, %1, 1"
-#define A_LERP(n) "v_lerp_u8 %0, %0, %1, %2"
-#define A_SADU8(n) "v_sad_u8 %0, %0, %1, %2"
-#define A_FMA(n) "v_fma_f32 %0, %0, %1, %2"
-#define A_MOV(n) "v_mov_b32 %0, %1"
-#define A_PKMAD(n) "v_pk_mad_u16 %0, %0, %1, %2"
-#define A_PKLSHR(n) "v_pk_lshrrev_b16 %0, 4, %0"
-#define A_DOT4(n) "v_dot4_u32_u8 %0, %0, %1, %2"
-#define A_MSAD(n) "v_msad_u8 %0, %0, %1, %2"
+#define STR2(x) #x
+#define STR(x) STR2(x)
+// instruction forms; n = accumulator register number
+#define O_ADD(n) "v_add_u32 v" STR(n) ", v" STR(n) ", v18"
+#define O_SUB(n) "v_sub_u32 v" STR(n) ", v" STR(n) ", v18"
+#define O_AND(n) "v_and_b32 v" STR(n) ", v" STR(n) ", v18"
+#define O_OR(n) "v_or_b32 v" STR(n) ", v" STR(n) ", v18"
+#define O_LSHR(n) "v_lshrrev_b32 v" STR(n) ", 3, v" STR(n)
+#define O_LSHL(n) "v_lshlrev_b32 v" STR(n) ", 3, v" STR(n)
+#define O_MOV(n) "v_mov_b32 v" STR(n) ", v18"
+#define O_ADD3(n) "v_add3_u32 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_ANDOR(n) "v_and_or_b32 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_BFI(n) "v_bfi_b32 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_PERM(n) "v_perm_b32 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_PKMIN(n) "v_pk_min_u16 v" STR(n) ", v" STR(n) ", v18"
+#define O_PKMAX(n) "v_pk_max_u16 v" STR(n) ", v" STR(n) ", v18"
+#define O_PKADD(n) "v_pk_add_u16 v" STR(n) ", v" STR(n) ", v18"
+#define O_PKSUBC(n) "v_pk_sub_u16 v" STR(n) ", v" STR(n) ", v18 clamp"
+#define O_MINU(n) "v_min_u32 v" STR(n) ", v" STR(n) ", v18"
+#define O_MUL24(n) "v_mul_u32_u24 v" STR(n) ", v" STR(n) ", v18"
+#define O_SADU16(n) "v_sad_u16 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_SADU8(n) "v_sad_u8 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_LERP(n) "v_lerp_u8 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_ALIGNBYTE(n) "v_alignbyte_b32 v" STR(n) ", v" STR(n) ", v18, 1"
+#define O_CNDS(n) "v_cndmask_b32 v" STR(n) ", v" STR(n) ", v18, s[10:11]"
+#define O_FMA(n) "v_fma_f32 v" STR(n) ", v" STR(n) ", v18, v19"
+#define O_ADDF(n) "v_add_f32 v" STR(n) ", v" STR(n) ", v18"
+#define O_MAXU16(n) "v_max_u16 v" STR(n) ", v" STR(n) ", v18"
+#define O_BFE(n) "v_bfe_u32 v" STR(n) ", v" STR(n) ", 3, 8"
+#define O_BITOP3(n) "v_bitop3_b32 v" STR(n) ", v" STR(n) ", v18, v19 bitop3:0xca"
+// DPP forms read the neighbouring lane's accumulator; the source must not have been written by the two
+// preceding VALU instructions (a hardware hazard the assembler does not pad), so they only exist in `ind` form
+#define O_ADDDPP(n) "v_add_u32_dpp v" STR(n) ", v18, v" STR(n) " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define O_MOVDPP(n) "v_mov_b32_dpp v" STR(n) ", v18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define O_ADDSDWA(n) "v_add_u32_sdwa v" STR(n) ", v" STR(n) ", v18 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
 
-DEFK(add, A_ADD) DEFK(add3, A_ADD3) DEFK(sad_u16, A_SAD) DEFK(bfe, A_BFE) DEFK(lshl_or, A_LSHLOR)
-DEFK(min, A_MIN) DEFK(min3, A_MIN3) DEFK(add_dpp_wave, A_ADDDPP) DEFK(add_dpp_row, A_ADDDPPROW)
-DEFK(mov_dpp_wave, A_MOVDPP) DEFK(add_sdwa, A_ADDSDWA) DEFK(pk_add_u16, A_PKADD) DEFK(pk_sub_opsel, A_PKSUB)
-DEFK(pk_max_i16, A_PKMAX) DEFK(cndmask, A_CNDMASK) DEFK(mul_u24, A_MUL24) DEFK(mad_u24, A_MAD24)
-DEFK(and_b32, A_AND) DEFK(and_or, A_ANDOR) DEFK(perm, A_PERM) DEFK(alignbyte, A_ALIGNBYTE) DEFK(lerp_u8, A_LERP)
-DEFK(sad_u8, A_SADU8) DEFK(fma_f32, A_FMA) DEFK(mov, A_MOV) DEFK(pk_mad_u16, A_PKMAD) DEFK(pk_lshr, A_PKLSHR)
-DEFK(dot4_u8, A_DOT4) DEFK(msad_u8, A_MSAD)
+#define KIND(NAME, OP) DEFK(NAME##_ind, R16(IND8(OP))) DEFK(NAME##_dep, R16(DEP8(OP))) DEFK(NAME##_dep2, R16(DEP2_8(OP)))
+KIND(add, O_ADD) KIND(sub, O_SUB) KIND(and, O_AND) KIND(or, O_OR) KIND(lshr, O_LSHR) KIND(lshl, O_LSHL) KIND(mov, O_MOV)
+KIND(add3, O_ADD3) KIND(and_or, O_ANDOR) KIND(bfi, O_BFI) KIND(perm, O_PERM) KIND(pk_min_u16, O_PKMIN)
+KIND(pk_max_u16, O_PKMAX) KIND(pk_add_u16, O_PKADD) KIND(pk_sub_u16_clamp, O_PKSUBC) KIND(min_u32, O_MINU)
+KIND(mul_u24, O_MUL24) KIND(sad_u16, O_SADU16) KIND(sad_u8, O_SADU8) KIND(lerp_u8, O_LERP) KIND(alignbyte, O_ALIGNBYTE)
+KIND(cndmask_sgpr, O_CNDS) KIND(fma_f32, O_FMA) KIND(add_f32, O_ADDF) KIND(max_u16, O_MAXU16) KIND(bfe_u32, O_BFE)
+KIND(bitop3, O_BITOP3) KIND(add_sdwa, O_ADDSDWA)
+DEFK(add_dpp_ind, R16(IND8(O_ADDDPP))) DEFK(mov_dpp_ind, R16(IND8(O_MOVDPP)))
 
+// s_nop 0 after every instruction: what round 1's table measured
+#define O_ADDNOP(n) O_ADD(n) "\n\ts_nop 0"
+#define O_PKMINNOP(n) O_PKMIN(n) "\n\ts_nop 0"
+DEFK(add_nop_ind, R16(IND8(O_ADDNOP))) DEFK(pk_min_nop_ind, R16(IND8(O_PKMINNOP)))
 
-#define A_SUB(n) "v_sub_u32 %0, %0, %1"
-#define A_SUBREV(n) "v_subrev_u32 %0, %0, %1"
-#define A_OR(n) "v_or_b32 %0, %0, %1"
-#define A_XOR(n) "v_xor_b32 %0, %0, %1"
-#define A_LSHL(n) "v_lshlrev_b32 %0, 3, %0"
-#define A_LSHR(n) "v_lshrrev_b32 %0, 3, %0"
-#define A_ASHR(n) "v_ashrrev_i32 %0, 3, %0"
-#define A_MAXU(n) "v_max_u32 %0, %0, %1"
-#define A_MAXI(n) "v_max_i32 %0, %0, %1"
-#define A_MINI(n) "v_min_i32 %0, %0, %1"
-#define A_ADDF(n) "v_add_f32 %0, %0, %1"
-#define A_SUBF(n) "v_sub_f32 %0, %0, %1"
-#define A_MULF(n) "v_mul_f32 %0, %0, %1"
-#define A_MAXF(n) "v_max_f32 %0, %0, %1"
-#define A_MINF(n) "v_min_f32 %0, %0, %1"
-#define A_ADDFABS(n) "v_add_f32 %0, %0, |%1|"
-#define A_FMAC(n) "v_fmac_f32 %0, %1, %2"
-#define A_MIN3F(n) "v_min3_f32 %0, %0, %1, %2"
-#define A_MED3F(n) "v_med3_f32 %0, %0, %1, %2"
-#define A_FLOORF(n) "v_floor_f32 %0, %0"
-#define A_FRACTF(n) "v_fract_f32 %0, %0"
-#define A_CVTU(n) "v_cvt_u32_f32 %0, %0"
-#define A_CVTF(n) "v_cvt_f32_u32 %0, %0"
-#define A_CVTUB0(n) "v_cvt_f32_ubyte0 %0, %1"
-#define A_CVTUB2(n) "v_cvt_f32_ubyte2 %0, %1"
-#define A_CVTPKU8(n) "v_cvt_pk_u8_f32 %0, %1, 1, %0"
-#define A_ADDU16(n) "v_add_u16 %0, %0, %1"
-#define A_SUBU16(n) "v_sub_u16 %0, %0, %1"
-#define A_MAXU16(n) "v_max_u16 %0, %0, %1"
-#define A_MINU16(n) "v_min_u16 %0, %0, %1"
-#define A_LSHRB16(n) "v_lshrrev_b16 %0, 4, %0"
-#define A_MULLOU16(n) "v_mul_lo_u16 %0, %0, %1"
-#define A_MADU16(n) "v_mad_u16 %0, %0, %1, %2"
-#define A_CNDS(n) "v_cndmask_b32 %0, %0, %1, s[10:11]"
-#define A_ADDCO(n) "v_add_co_u32 %0, vcc, %0, %1"
-#define A_LSHLADD(n) "v_lshl_add_u32 %0, %0, 2, %1"
-#define A_ADDLSHL(n) "v_add_lshl_u32 %0, %0, %1, 2"
-#define A_BFI(n) "v_bfi_b32 %0, %0, %1, %2"
-#define A_ALIGNBIT(n) "v_alignbit_b32 %0, %0, %1, 16"
-#define A_PKMIN(n) "v_pk_min_u16 %0, %0, %1"
-#define A_PKADDF16(n) "v_pk_add_f16 %0, %0, %1"
-#define A_PKFMAF16(n) "v_pk_fma_f16 %0, %0, %1, %2"
-#define A_PKADDF32(n) "v_pk_add_f32 %0, %0, %1"
-#define A_XAD(n) "v_xad_u32 %0, %0, %1, %2"
-#define A_MAX3U(n) "v_max3_u32 %0, %0, %1, %2"
-#define A_READLANE(n) "v_readlane_b32 s12, %0, 3"
-#define A_MBCNT(n) "v_mbcnt_lo_u32_b32 %0, %1, %0"
-#define A_ADDF16(n) "v_add_f16 %0, %0, %1"
-#define A_MAXF16(n) "v_max_f16 %0, %0, %1"
-#define A_CVTF16(n) "v_cvt_f16_f32 %0, %0"
-#define A_ADDE64(n) "v_add_u32_e64 %0, %0, %1"
-#define A_ANDE64(n) "v_and_b32_e64 %0, %0, %1"
+// mixes: F = fast form, S = slow form.  `mix30` has the sweep's share of slow forms (3 in 10, spread out),
+// `mix30_dep` the same with the fast instructions in ONE dependent chain (the sliding box sum), `mix50` every other.
+#define MIX8_30(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_AND(b), O_PKMIN(c), O_SUB(d), O_LSHR(e), O_PKMAX(f), O_OR(g), O_ADD(h))
+#define MIX8_25(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_AND(b), O_PKMIN(c), O_SUB(d), O_LSHR(e), O_ADD(f), O_BFI(g), O_ADD(h))
+DEFK(mix_f6s2_ind, R16(MIX8_30(10, 11, 12, 13, 14, 15, 16, 17)))
+DEFK(mix_f6s2_dep, R16(MIX8_30(10, 10, 11, 10, 10, 12, 10, 10)))
+DEFK(mix_f6s2b_ind, R16(MIX8_25(10, 11, 12, 13, 14, 15, 16, 17)))
+#define MIX8_50(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_PKMIN(b), O_AND(c), O_PKMAX(d), O_SUB(e), O_BFI(f), O_LSHR(g), O_PERM(h))
+DEFK(mix_f4s4_ind, R16(MIX8_50(10, 11, 12, 13, 14, 15, 16, 17)))
+// slow forms in pairs / in runs of four (how the compiler emits the abs-diff block) against spread out
+#define MIX8_PAIR(a, b, c, d, e, f, g, h) X8(O_PKMAX(a), O_PKMIN(b), O_SUB(c), O_ADD(d), O_ADD(e), O_SUB(f), O_AND(g), O_LSHR(h))
+DEFK(mix_s2f6_ind, R16(MIX8_PAIR(10, 11, 12, 13, 14, 15, 16, 17)))
+// SALU in between: scalar instructions take an issue slot of the wave, not the vector pipe
+#define O_SADD(n) "s_add_u32 s10, s10, 1"
+#define MIX8_SALU(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_AND(b), O_SADD(c), O_SUB(d), O_LSHR(e), O_SADD(f), O_OR(g), O_ADD(h))
+DEFK(mix_f6salu2_ind, R16(MIX8_SALU(10, 11, 12, 13, 14, 15, 16, 17)))
 
-DEFK(sub, A_SUB) DEFK(subrev, A_SUBREV) DEFK(or_b32, A_OR) DEFK(xor_b32, A_XOR) DEFK(lshl, A_LSHL) DEFK(lshr, A_LSHR) DEFK(ashr, A_ASHR) DEFK(max_u32, A_MAXU) DEFK(max_i32, A_MAXI) DEFK(min_i32, A_MINI) DEFK(add_f32, A_ADDF) DEFK(sub_f32, A_SUBF) DEFK(mul_f32, A_MULF) DEFK(max_f32, A_MAXF) DEFK(min_f32, A_MINF) DEFK(add_f32_abs, A_ADDFABS) DEFK(fmac_f32, A_FMAC) DEFK(min3_f32, A_MIN3F) DEFK(med3_f32, A_MED3F) DEFK(floor_f32, A_FLOORF) DEFK(fract_f32, A_FRACTF) DEFK(cvt_u32_f32, A_CVTU) DEFK(cvt_f32_u32, A_CVTF) DEFK(cvt_f32_ubyte0, A_CVTUB0) DEFK(cvt_f32_ubyte2, A_CVTUB2) DEFK(cvt_pk_u8_f32, A_CVTPKU8) DEFK(add_u16, A_ADDU16) DEFK(sub_u16, A_SUBU16) DEFK(max_u16, A_MAXU16) DEFK(min_u16, A_MINU16) DEFK(lshr_b16, A_LSHRB16) DEFK(mul_lo_u16, A_MULLOU16) DEFK(mad_u16, A_MADU16) DEFK(cndmask_sgpr, A_CNDS) DEFK(add_co, A_ADDCO) DEFK(lshl_add, A_LSHLADD) DEFK(add_lshl, A_ADDLSHL) DEFK(bfi, A_BFI) DEFK(alignbit, A_ALIGNBIT) DEFK(pk_min_u16, A_PKMIN) DEFK(pk_add_f16, A_PKADDF16) DEFK(pk_fma_f16, A_PKFMAF16) DEFK(xad, A_XAD) DEFK(max3_u32, A_MAX3U) DEFK(mbcnt, A_MBCNT) DEFK(add_f16, A_ADDF16) DEFK(max_f16, A_MAXF16) DEFK(cvt_f16_f32, A_CVTF16) DEFK(add_e64, A_ADDE64) DEFK(and_e64, A_ANDE64)
+// ---- second series: how the mix matters -------------------------------------------------------------------
+// different fast opcodes only (no slow form at all)
+#define FMIX8(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_AND(b), O_SUB(c), O_LSHR(d), O_OR(e), O_ADD(f), O_AND(g), O_SUB(h))
+DEFK(fastmix_ind, R16(FMIX8(10, 11, 12, 13, 14, 15, 16, 17)))
+DEFK(fastmix_dep, R16(FMIX8(10, 10, 10, 10, 10, 10, 10, 10)))
+// share of slow forms: 1 in 32, 1 in 16, 1 in 8 (the rest different fast opcodes)
+#define FMIX8_S1(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_AND(b), O_SUB(c), O_PKMIN(d), O_OR(e), O_ADD(f), O_AND(g), O_SUB(h))
+#define FMIX8_D1(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_AND(b), O_SUB(c), O_ADDDPP(d), O_OR(e), O_ADD(f), O_AND(g), O_SUB(h))
+#define FMIX8_B1(a, b, c, d, e, f, g, h) X8(O_ADD(a), O_AND(b), O_SUB(c), O_BFI(d), O_OR(e), O_ADD(f), O_AND(g), O_SUB(h))
+#define FM FMIX8(10, 11, 12, 13, 14, 15, 16, 17)
+#define FS FMIX8_S1(10, 11, 12, 13, 14, 15, 16, 17)
+#define FD FMIX8_D1(10, 11, 12, 13, 14, 15, 16, 17)
+#define FB FMIX8_B1(10, 11, 12, 13, 14, 15, 16, 17)
+DEFK(slow1in32, FM FM FM FS FM FM FM FS FM FM FM FS FM FM FM FS)
+DEFK(slow1in16, FM FS FM FS FM FS FM FS FM FS FM FS FM FS FM FS)
+DEFK(slow1in8, R16(FS))
+DEFK(dpp1in8, R16(FD))
+DEFK(bfi1in8, R16(FB))
+// slow forms bunched: 16 in a row, then 112 fast (same 1-in-8 share)
+#define S8 IND8(O_PKMIN)
+DEFK(slow16_fast112, S8 S8 FM FM FM FM FM FM FM FM FM FM FM FM FM FM)
+// 32 slow in a row, then 96 fast (1 in 4)
+DEFK(slow32_fast96, S8 S8 S8 S8 FM FM FM FM FM FM FM FM FM FM FM FM)
+// the sweep's own opcode mix (k_fused_u8_v3<4,0> main loop: and 18 %, add 18 %, lshr 11 %, sub 9 %, or 7 %, pk_min 8 %,
+// pk_max 4 %, add3 4 %, and_or 4 %, DPP 5 %, bfi 2 %, perm 1 %, mul_u24 2 %, lshl 1 %), 32-instruction pattern
+#define SW32 X8(O_PKMAX(10), O_PKMIN(11), O_SUB(12), O_ADD(13), O_ADD(14), O_SUB(15), O_AND(16), O_LSHR(17)) \
+             X8(O_ADD(10), O_OR(11), O_PKMIN(12), O_AND(13), O_LSHR(14), O_ADDDPP(15), O_ADD3(16), O_AND(17)) \
+             X8(O_PKMAX(10), O_PKMIN(11), O_SUB(12), O_ADD(13), O_ANDOR(14), O_AND(15), O_LSHR(16), O_OR(17)) \
+             X8(O_ADD(10), O_AND(11), O_BFI(12), O_MUL24(13), O_LSHR(14), O_ADDDPP(15), O_ADD(16), O_AND(17))
+DEFK(sweepmix, SW32 SW32 SW32 SW32)
+// the same without its packed min/max (as if |a-b| and the key minimum came for free): what is left of the slow forms
+#define SW32B X8(O_ADD(10), O_ADD(11), O_SUB(12), O_ADD(13), O_ADD(14), O_SUB(15), O_AND(16), O_LSHR(17)) \
+              X8(O_ADD(10), O_OR(11), O_AND(12), O_AND(13), O_LSHR(14), O_ADDDPP(15), O_ADD3(16), O_AND(17)) \
+              X8(O_SUB(10), O_ADD(11), O_SUB(12), O_ADD(13), O_ANDOR(14), O_AND(15), O_LSHR(16), O_OR(17)) \
+              X8(O_ADD(10), O_AND(11), O_BFI(12), O_MUL24(13), O_LSHR(14), O_ADDDPP(15), O_ADD(16), O_AND(17))
+DEFK(sweepmix_nopk, SW32B SW32B SW32B SW32B)
+// two-operand 16-bit forms on the low halves (fast class) as a replacement for packed min / max
+#define O_MINU16(n) "v_min_u16 v" STR(n) ", v" STR(n) ", v18"
+#define O_SUBU16(n) "v_sub_u16 v" STR(n) ", v" STR(n) ", v18"
+#define O_LSHLB16(n) "v_lshlrev_b16 v" STR(n) ", 4, v" STR(n)
+#define O_NOT(n) "v_not_b32 v" STR(n) ", v" STR(n)
+#define O_XOR(n) "v_xor_b32 v" STR(n) ", v" STR(n) ", v18"
+#define O_ASHR(n) "v_ashrrev_i32 v" STR(n) ", 3, v" STR(n)
+#define O_SUBREV(n) "v_subrev_u32 v" STR(n) ", v" STR(n) ", v18"
+#define O_ADDC(n) "v_addc_co_u32 v" STR(n) ", vcc, v" STR(n) ", v18, vcc"
+#define O_MAXI16(n) "v_max_i16 v" STR(n) ", v" STR(n) ", v18"
+#define O_CNDV(n) "v_cndmask_b32 v" STR(n) ", v" STR(n) ", v18, vcc"
+#define O_MULLO16(n) "v_mul_lo_u16 v" STR(n) ", v" STR(n) ", v18"
+#define O_ADDF16(n) "v_add_f16 v" STR(n) ", v" STR(n) ", v18"
+#define O_MULF(n) "v_mul_f32 v" STR(n) ", v" STR(n) ", v18"
+#define O_FMAC(n) "v_fmac_f32 v" STR(n) ", v18, v19"
+#define O_MAXF(n) "v_max_f32 v" STR(n) ", v" STR(n) ", v18"
+#define O_CVTU8(n) "v_cvt_f32_ubyte0 v" STR(n) ", v" STR(n)
+#define O_ADDLIT(n) "v_add_u32 v" STR(n) ", 0x12345, v" STR(n)
+#define O_ANDLIT(n) "v_and_b32 v" STR(n) ", 0xff00ff, v" STR(n)
+#define O_ADDE64(n) "v_add_u32_e64 v" STR(n) ", v" STR(n) ", s10"
+#define O_ADDSG(n) "v_add_u32 v" STR(n) ", s10, v" STR(n)
+KIND(min_u16, O_MINU16) KIND(sub_u16, O_SUBU16) KIND(lshl_b16, O_LSHLB16) KIND(not_b32, O_NOT) KIND(xor_b32, O_XOR)
+KIND(ashr, O_ASHR) KIND(subrev, O_SUBREV) KIND(max_i16, O_MAXI16) KIND(cndmask_vcc, O_CNDV) KIND(mul_lo_u16, O_MULLO16)
+KIND(add_f16, O_ADDF16) KIND(mul_f32, O_MULF) KIND(fmac_f32, O_FMAC) KIND(max_f32, O_MAXF) KIND(cvt_f32_ubyte0, O_CVTU8)
+KIND(add_literal, O_ADDLIT) KIND(and_literal, O_ANDLIT) KIND(add_e64_sgpr, O_ADDE64) KIND(add_sgpr, O_ADDSG)
 
-// 64-bit result forms (qsad): separate kernel shape
-__global__ void __launch_bounds__(1024) k_qsad(unsigned* out, int iters)
-{
-    unsigned long long r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, s = r0 * 7 + 3;
-    unsigned b = threadIdx.x * 5 + 2;
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(r0) : "v"(s), "v"(b));
-            asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(r1) : "v"(s), "v"(b));
-            asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(r2) : "v"(s), "v"(b));
-            asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(r3) : "v"(s), "v"(b));
-        }
-    }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(r0 ^ r1 ^ r2 ^ r3);
-}
-
-typedef void (*kern_t)(unsigned*, int);
-struct Entry { const char* name; kern_t k; int per_iter; };
+typedef void (*kern_t)(unsigned long long*, int);
+struct Entry {
+    const char* name;
+    kern_t k;
+};
 
 int main(int argc, char** argv)
 {
-    Entry es[] = {
-#define E(n) {#n, k_##n, 64},
-        E(add) E(add3) E(sad_u16) E(bfe) E(lshl_or) E(min) E(min3) E(add_dpp_wave) E(add_dpp_row) E(mov_dpp_wave)
-        E(add_sdwa) E(pk_add_u16) E(pk_sub_opsel) E(pk_max_i16) E(cndmask) E(mul_u24) E(mad_u24) E(and_b32) E(and_or)
-        E(perm) E(alignbyte) E(lerp_u8) E(sad_u8) E(fma_f32) E(mov) E(pk_mad_u16) E(pk_lshr) E(dot4_u8) E(msad_u8)
-        E(sub) E(subrev) E(or_b32) E(xor_b32) E(lshl) E(lshr) E(ashr) E(max_u32) E(max_i32) E(min_i32) E(add_f32) E(sub_f32) E(mul_f32) E(max_f32) E(min_f32) E(add_f32_abs) E(fmac_f32) E(min3_f32) E(med3_f32) E(floor_f32) E(fract_f32) E(cvt_u32_f32) E(cvt_f32_u32) E(cvt_f32_ubyte0) E(cvt_f32_ubyte2) E(cvt_pk_u8_f32) E(add_u16) E(sub_u16) E(max_u16) E(min_u16) E(lshr_b16) E(mul_lo_u16) E(mad_u16) E(cndmask_sgpr) E(add_co) E(lshl_add) E(add_lshl) E(bfi) E(alignbit) E(pk_min_u16) E(pk_add_f16) E(pk_fma_f16) E(xad) E(max3_u32) E(mbcnt) E(add_f16) E(max_f16) E(cvt_f16_f32) E(add_e64) E(and_e64)
-        {"qsad_pk_u16_u8", k_qsad, 64},
+    std::vector<Entry> es = {
+#define E3(n) {#n " ind", k_##n##_ind}, {#n " dep", k_##n##_dep}, {#n " dep2", k_##n##_dep2},
+        E3(add) E3(sub) E3(and) E3(or) E3(lshr) E3(mov) E3(fma_f32) E3(add_f32) E3(max_u16)
+        E3(lshl) E3(add3) E3(and_or) E3(bfi) E3(bitop3) E3(perm) E3(pk_min_u16) E3(pk_max_u16) E3(pk_add_u16) E3(pk_sub_u16_clamp)
+        E3(min_u32) E3(mul_u24) E3(sad_u16) E3(sad_u8) E3(lerp_u8) E3(alignbyte) E3(cndmask_sgpr) E3(bfe_u32) E3(add_sdwa)
+        {"add_dpp ind", k_add_dpp_ind}, {"mov_dpp ind", k_mov_dpp_ind},
+        {"add+s_nop ind", k_add_nop_ind}, {"pk_min+s_nop ind", k_pk_min_nop_ind},
+        {"mix 6 fast 2 slow ind", k_mix_f6s2_ind}, {"mix 6 fast(dep) 2 slow", k_mix_f6s2_dep},
+        {"mix 6 fast 2 slow(b) ind", k_mix_f6s2b_ind}, {"mix 4 fast 4 slow ind", k_mix_f4s4_ind},
+        {"mix slow pair + 6 fast", k_mix_s2f6_ind}, {"mix 6 fast 2 salu", k_mix_f6salu2_ind},
+        {"fast opcodes mixed ind", k_fastmix_ind}, {"fast opcodes mixed dep", k_fastmix_dep},
+        {"slow 1 in 32", k_slow1in32}, {"slow 1 in 16", k_slow1in16}, {"slow 1 in 8 (pk_min)", k_slow1in8},
+        {"slow 1 in 8 (add_dpp)", k_dpp1in8}, {"slow 1 in 8 (bfi)", k_bfi1in8},
+        {"16 slow then 112 fast", k_slow16_fast112}, {"32 slow then 96 fast", k_slow32_fast96},
+        {"sweep opcode mix", k_sweepmix}, {"sweep mix w/o pk min/max", k_sweepmix_nopk},
+        E3(min_u16) E3(sub_u16) E3(lshl_b16) E3(not_b32) E3(xor_b32) E3(ashr) E3(subrev) E3(max_i16) E3(cndmask_vcc)
+        E3(mul_lo_u16) E3(add_f16) E3(mul_f32) E3(fmac_f32) E3(max_f32) E3(cvt_f32_ubyte0) E3(add_literal) E3(and_literal)
+        E3(add_e64_sgpr) E3(add_sgpr)
     };
+    // optional arguments: substrings of the names to run
     hipDeviceProp_t prop;
-    hipGetDeviceProperties(&prop, 0);
+    (void)hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
-    const double ghz = prop.clockRate * 1e-6;
-    unsigned* out;
-    hipMalloc(&out, (size_t)cus * 1024 * 4 * sizeof(unsigned));
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    const int iters = 4000;
-    printf("# %s, %d CUs, clock %.2f GHz; cycles per wave-instruction per SIMD (nominal clock)\n", prop.name, cus, ghz);
-    printf("%-18s %8s %8s %8s\n", "instruction", "1w/SIMD", "2w/SIMD", "4w/SIMD");
+    unsigned long long* out;
+    const size_t n_out = (size_t)cus * 2 * 1024;
+    (void)hipMalloc(&out, n_out * sizeof(unsigned long long));
+    std::vector<unsigned long long> host(n_out);
+    const int iters = 2000;
+    const int per_iter = 128;
+    printf("# %s, %d CUs; cycles per wave-instruction per SIMD (s_memtime inside the kernel), %d-instruction asm body x %d\n",
+           prop.name, cus, per_iter, iters);
+    printf("%-28s %7s %7s %7s %7s %7s\n", "instruction", "1w", "2w", "3w", "4w", "8w");
     for (auto& e : es) {
-        printf("%-18s", e.name);
-        for (int wps : {1, 2, 4}) {
-            const int threads = wps * 4 * 64;  // waves per CU = wps * 4 SIMDs, one block per CU
-            hipLaunchKernelGGL(e.k, dim3(cus), dim3(threads), 0, 0, out, 10);
-            hipDeviceSynchronize();
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(e.k, dim3(cus), dim3(threads), 0, 0, out, iters);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
-            float ms;
-            hipEventElapsedTime(&ms, e0, e1);
-            const double instr_per_simd = (double)wps * iters * e.per_iter;
-            printf(" %8.2f", ms * 1e-3 * ghz * 1e9 / instr_per_simd);
+        bool want = argc <= 1;
+        for (int i = 1; i < argc; ++i) want = want || strstr(e.name, argv[i]);
+        if (!want) continue;
+        printf("%-28s", e.name);
+        for (int wps : {1, 2, 3, 4, 8}) {
+            // waves per CU = wps * 4 SIMDs; one block per CU up to 1024 threads, two blocks per CU for 8
+            const int blocks = wps == 8 ? 2 * cus : cus;
+            const int threads = wps == 8 ? 1024 : wps * 256;
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, 10);
+            (void)hipDeviceSynchronize();
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, iters);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(host.data(), out, (size_t)blocks * threads * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            // median over waves of the wave's own cycle count
+            std::vector<unsigned long long> cyc;
+            for (size_t i = 0; i < (size_t)blocks * threads; i += 64) cyc.push_back(host[i] >> 8);
+            std::nth_element(cyc.begin(), cyc.begin() + cyc.size() / 2, cyc.end());
+            const double wave_cycles = (double)cyc[cyc.size() / 2];
+            printf(" %7.2f", wave_cycles / ((double)iters * per_iter) / wps);
         }
         printf("\n");
+        fflush(stdout);
     }
     return 0;
 }
