@@ -46,6 +46,7 @@ struct LaneRole {
     bool line_last;  // lane owns the last column of the source lines (kChroma: region_w - 1)
     bool inside;     // kChroma: the lane's columns lie inside the chroma region
     unsigned first_mask, last_mask;  // all ones where first / last
+    unsigned key_mask;               // 0xffff0 in a VGPR (operand of the and-or that forms the ladder keys)
 };
 
 __device__ __forceinline__ void unpack(Line& L, const Raw& q, const LaneRole& role)
@@ -93,6 +94,23 @@ __device__ __forceinline__ unsigned cost(const Line& c, const Line& n, int j)
     if constexpr (BUF == 6) return absdiff(c.P[i + 1], n.P[i - 1]);
     if constexpr (BUF == 7) return absdiff(c.P[i + 2], n.P[i - 2]);
     return absdiff(c.P[i + 3], n.P[i - 3]);
+}
+
+// acc + cost<BUF>: v_sad_u16 adds its third operand, so S = A + D and A' = O + D are ONE instruction each and D itself
+// never exists (with two waves per SIMD an instruction costs the same whatever it does: fewer is faster)
+template <int BUF>
+__device__ __forceinline__ unsigned cost_acc(const Line& c, const Line& n, int j, unsigned acc)
+{
+    const int i = j + 3;
+    if constexpr (BUF == 0) return __builtin_amdgcn_sad_u16(c.P[i - 3], n.P[i + 3], acc);
+    if constexpr (BUF == 1) return __builtin_amdgcn_sad_u16(c.P[i - 2], n.P[i + 2], acc);
+    if constexpr (BUF == 2) return __builtin_amdgcn_sad_u16(c.P[i - 1], n.P[i + 1], acc);
+    if constexpr (BUF == 3) return __builtin_amdgcn_sad_u16(c.F(j), n.B(j), acc);
+    if constexpr (BUF == 4) return __builtin_amdgcn_sad_u16(c.P[i], n.P[i], acc);
+    if constexpr (BUF == 5) return __builtin_amdgcn_sad_u16(c.B(j), n.F(j), acc);
+    if constexpr (BUF == 6) return __builtin_amdgcn_sad_u16(c.P[i + 1], n.P[i - 1], acc);
+    if constexpr (BUF == 7) return __builtin_amdgcn_sad_u16(c.P[i + 2], n.P[i - 2], acc);
+    return __builtin_amdgcn_sad_u16(c.P[i + 3], n.P[i - 3], acc);
 }
 
 template <int BUF>
@@ -180,6 +198,21 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
                                             const LaneRole& role, const PoolIO& io, const RowCtx& rc, const u32x4& stale)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
+    if constexpr (MODE == kPlain || MODE == kLumaSpill) {
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) S[j] = S1 ? cost_acc<BUF>(n, nn, j, A[j]) : A[j];
+        if (role.edge_wave) box7<true>(S, Bx, role);
+        else box7<false>(S, Bx, role);
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF>());  // (sum / 16 mod 65536) << 4 | rank
+            O[j] = key >> 4;                                                     // SangNom2.cpp:152
+            A[j] = S1 ? cost_acc<BUF>(n, nn, j, O[j]) : O[j];
+            kmin[j] = umin(kmin[j], key);
+        }
+        if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
+        return;
+    }
     if constexpr (MODE == kChroma) {
         io.finish(stale, D);
         if constexpr (S1) {
@@ -375,6 +408,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     role.last = live && gl == a.nl - 1;
     role.line_last = line_live && x0 + PXL == line_w;
     role.inside = line_live;
+    role.key_mask = 0xffff0u;
     role.first_mask = role.first ? 0xffffffffu : 0u;
     role.last_mask = role.last ? 0xffffffffu : 0u;
     role.edge_wave = __builtin_amdgcn_readfirstlane(__any((int)(role.first || role.last || role.line_last)) ? 1 : 0) != 0;

@@ -82,6 +82,7 @@ struct LaneRole {
     unsigned last_mask;  // 0xffff (shifted) in the half that owns column w-1 of the sweep
     unsigned line_last_mask;  // ... that owns the last column of the source lines (kChroma: region_w - 1)
     unsigned inside_mask;     // kChroma: halves whose columns lie inside the chroma region
+    unsigned key_mask;        // 0x0ff00ff0 in a VGPR (operand of the and-or that forms the ladder keys)
 };
 
 // byte k of the lo word -> bits 0..7, byte k of the hi word -> bits 16..23
@@ -279,10 +280,22 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
     else box7<false>(S, Bx, role);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        const unsigned t = Bx[j] & 0x0ff00ff0u;  // O << 4; shared by O and the key: three full-rate ops
-        O[j] = t >> 4;                           // (sum / 16) wraps to uint8_t, SangNom2.cpp:152
-        A[j] = O[j] + D[j];                      // O + D[r+1]
-        kmin[j] = pk_min(kmin[j], t | rank_of<BUF>());
+        if constexpr (has_pools(MODE)) {
+            // the pool-coupled modes sit at the register limit; this form allocates best there
+            const unsigned t = Bx[j] & 0x0ff00ff0u;  // O << 4, shared by O and the key
+            O[j] = t >> 4;                           // (sum / 16) wraps to uint8_t, SangNom2.cpp:152
+            A[j] = O[j] + D[j];                      // O + D[r+1]
+            kmin[j] = pk_min(kmin[j], t | rank_of<BUF>());
+        } else {
+            // key = (sum / 16 mod 256) << 4 | rank in ONE v_and_or_b32; the rank (< 16) falls off the PACKED shift that
+            // yields O (a 32-bit shift would push the high half's rank into the low half).  With two waves per SIMD
+            // every VALU instruction costs about the same (profiles/r2_ubench_valu_issue_rates.txt), so what counts is
+            // the NUMBER of instructions: 4 here, 5 above.
+            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF>());
+            O[j] = pk_lshr4(key);
+            A[j] = O[j] + D[j];
+            kmin[j] = pk_min(kmin[j], key);
+        }
     }
     if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
 }
@@ -391,10 +404,13 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
         const unsigned wk = kmin[j];
-        const unsigned m0 = (wk & 0x00010001u) * 0xffffu;
-        const unsigned m1 = ((wk >> 1) & 0x00010001u) * 0xffffu;
-        const unsigned m2 = ((wk >> 2) & 0x00010001u) * 0xffffu;
-        const unsigned m3 = ((wk >> 3) & 0x00010001u) * 0xffffu;
+        // rank bit k of each half -> a mask over that half: packed shift left to the sign bit, packed arithmetic
+        // shift back (two instructions per mask)
+        // (not in the pool-coupled modes: they sit at the register limit, and there the plain form allocates better)
+        const unsigned m0 = has_pools(MODE) ? (wk & 0x00010001u) * 0xffffu : pk_bit_mask<0>(wk);
+        const unsigned m1 = has_pools(MODE) ? ((wk >> 1) & 0x00010001u) * 0xffffu : pk_bit_mask<1>(wk);
+        const unsigned m2 = has_pools(MODE) ? ((wk >> 2) & 0x00010001u) * 0xffffu : pk_bit_mask<2>(wk);
+        const unsigned m3 = has_pools(MODE) ? ((wk >> 3) & 0x00010001u) * 0xffffu : pk_bit_mask<3>(wk);
         // ranks: 0,1 -> P4; 2 -> P5; 3 -> P3; 4 -> P6; 5 -> P2; 6 -> P7; 7 -> P1; 8 -> P8; 9 -> P0
         const unsigned a01 = tap_sum<4>(c, n, j);
         const unsigned a23 = bfi(m0, tap_sum<3>(c, n, j), tap_sum<5>(c, n, j));
@@ -405,7 +421,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
         const unsigned b1 = bfi(m1, a67, a45);
         const unsigned c0 = bfi(m2, b1, b0);
         const unsigned r = bfi(m3, a89, c0);
-        v[j] = ((r + 0x00010001u) >> 1) & kByte;  // (a + b + 1) >> 1
+        v[j] = has_pools(MODE) ? (((r + 0x00010001u) >> 1) & kByte) : pk_avg_from_sum(r);  // (a + b + 1) >> 1 in both halves
     }
     // v[j] = lo-strip byte | hi-strip byte << 16  ->  four bytes per dword and strip
 #pragma unroll
@@ -468,6 +484,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     role.last_mask = 0;
     role.line_last_mask = 0;
     role.inside_mask = 0;
+    role.key_mask = 0x0ff00ff0u;
     const int line_w = has_region(MODE) ? a.region_w : a.w;  // width of the source / destination plane
     bool line_live[2], line_real[2];
 #pragma unroll
@@ -662,8 +679,8 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             src_next += src_step;
         }
         const int par = (r / K) & 1;
-        if (r > 1 && (r - 1) % K == 0 && !(a.dbg & 1)) {
-            if (!(a.dbg & 4)) __syncthreads();
+        if (r > 1 && (r - 1) % K == 0) {
+            __syncthreads();
             if (recv_left || recv_right) {
                 const unsigned* from = reinterpret_cast<const unsigned*>(mb.at(par, wave, recv_left ? 0 : 1, slot));
                 auto merge = [&](int b, unsigned (&Ab)[PXL]) {
@@ -688,7 +705,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         pending = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
         if (r < sweep) {
-            if (r % K == 0 && !(a.dbg & 1)) {
+            if (r % K == 0) {
                 const int wpar = ((r + 1) / K) & 1;
                 if (pub_right || pub_left) {
                     // Inside the plane both halves of a seam register go to the same ghost lane of the neighbouring
@@ -738,7 +755,8 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
 
     // L1 = K[r] (n), L0 is reused for K[r+1] (nn); c lives in LDS.  Rows 1 .. nr-1 have a following line
     // pair, row nr does not (its next costs are zero or stale), rows beyond nr (kChroma only) have no
-    // interpolated line either.
+    // interpolated line either.  (Specialising the whole sweep on role.edge_wave -- two copies of the loop, no
+    // branch per buffer step -- was tried: the register allocator then spills in both copies.)
     for (int r = 1; r < nr; ++r) {
         step(r, L1, L0, T{}, T{});
         L1 = L0;
@@ -817,6 +835,9 @@ static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
 // pool->sweep_w is the luma width the sweep covers (p describes the plane being interpolated).
 hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool)
 {
+#ifdef SN_EXPERIMENT_V4  // A/B builds of tools/experiments only
+    if (!pool && fused_v4_plane_ok(p.w)) return launch_fused_u8_v4(st, p, threshold, nframes);
+#endif
     v3::Args a{};
     a.src = p.src;
     a.dst = p.dst;
@@ -834,8 +855,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.nw = (a.nvw + 1) / 2;
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
-    static const int dbg = [] { const char* e = getenv("SN_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
+    a.dbg = 0;
     a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
     a.nframes = nframes;
     if (!pool) return launch_mode<v3::kPlain>(st, a, nframes);
@@ -844,7 +864,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.pool_frame_stride = pool->frame_stride;
     a.pool_rows = pool->pool_rows;
     a.rows_in = pool->rows_in;
-    a.rows_out = (pool->pool_out && !(dbg & 8)) ? pool->rows_out : 0;  // dbg 8: timing without the hand-off stores (wrong results)
+    a.rows_out = pool->pool_out ? pool->rows_out : 0;
     a.region_w = p.w;
     a.sweep_rows = pool->sweep_rows;
     if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);

@@ -38,7 +38,7 @@ struct Args {
     int32_t nw;      // physical waves
     int32_t src_bytes;  // bytes of one source plane (buffer descriptor range)
     int32_t dst_bytes;  // bytes of one destination plane
-    int32_t dbg;        // timing experiments only (SN_FUSED_DEBUG): 1 = no seam refresh, 4 = refresh without its barrier, 8 = no hand-off stores (wrong results)
+    int32_t dbg;        // unused (kept for layout)
     // pool coupling for subsampled chroma (modes kLumaSpill / kChroma, see below)
     const uint8_t* pool_in;   // smoothed buffers left by the previous pass (kChroma)
     uint8_t* pool_out;        // where this pass leaves its smoothed buffers (kLumaSpill, first kChroma pass)
@@ -87,6 +87,44 @@ __device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+// Instruction selection the compiler cannot be talked into (it splits vector shifts into per-half selects, and its
+// demanded-bits analysis undoes a shared and-or): spelled out.  Plain `asm` (not volatile), so they are scheduled and
+// CSE'd like any other pure operation.
+// bit BIT of each 16-bit half spread over that half
+template <int BIT>
+__device__ __forceinline__ unsigned pk_bit_mask(unsigned v)
+{
+    unsigned m;
+    asm("v_pk_lshlrev_b16 %0, %2, %1 op_sel_hi:[0,1]\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(m) : "v"(v), "n"(15 - BIT));
+    return m;
+}
+// (s + 1) >> 1 in both halves (s < 65535)
+__device__ __forceinline__ unsigned pk_avg_from_sum(unsigned s)
+{
+    unsigned r;
+    asm("v_pk_add_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_lshrrev_b16 %0, 1, %0 op_sel_hi:[0,1]" : "=v"(r) : "v"(s));
+    return r;
+}
+// both halves shifted right by 4 (nothing crosses from the high half into the low one)
+__device__ __forceinline__ unsigned pk_lshr4(unsigned v)
+{
+    const u16x2 four = {4, 4};
+    return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, v) >> four));  // v_pk_lshrrev_b16
+}
+// (a & m) | c with a wave-uniform c (the one scalar operand the encoding allows)
+__device__ __forceinline__ unsigned and_or(unsigned a, unsigned m, unsigned c)
+{
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "s"(c));
+    return r;
+}
+// ... with a per-lane c
+__device__ __forceinline__ unsigned and_or_v(unsigned a, unsigned m, unsigned c)
+{
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(m), "v"(c));
+    return r;
+}
 // |a - b| in both halves (values < 32768 per half)
 __device__ __forceinline__ unsigned pk_absdiff(unsigned a, unsigned b) { return pk_max(a, b) - pk_min(a, b); }
 // (m & x) | (~m & y): v_bfi_b32
@@ -128,8 +166,6 @@ __host__ __device__ constexpr int group_of(int nw) { return nw == 1 ? 4 : nw == 
 // turns), and an 8-wave workgroup has both waves of every SIMD itself (they cannot drift apart; turns cost 1 %).
 inline int turn_shift_for(int nk, int waves)
 {
-    static const int forced = [] { const char* e = getenv("SN_TURN_SHIFT"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced;
     if (waves != 4) return 0;
     int s = 10;
     while ((128ll * nk) >> (s + 1)) ++s;

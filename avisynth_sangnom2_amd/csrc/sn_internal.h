@@ -73,6 +73,11 @@ int64_t fused_v3_pool_bytes(int sweep_w, int rows);
 // host: scatter one scratch pool (thread-slot layout) into [9][rows][sweep_w] samples (test hook)
 void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* out);
 hipError_t launch_fused_u8_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool);
+#ifdef SN_EXPERIMENT_V4  // tools/experiments/sn_fused_u8_v4.hip (four waves per SIMD; slower: profiles/r2_v4_experiment.md)
+bool fused_v4_plane_ok(int w);
+int fused_v4_waves(int w);
+hipError_t launch_fused_u8_v4(hipStream_t s, const PlaneArgs& p, double threshold, int nframes);
+#endif
 // sn_fused_u16_v3.hip: the same sweep for 9..16-bit samples (one pixel per register, up to 3840 wide).
 bool fused_u16_plane_ok(int w);
 // sn_fused_f32_v3.hip: the sweep for float samples (no chroma coupling: planes of equal size only).

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -28,7 +29,7 @@
 #define DEP2_8(OP) X8(OP(10), OP(11), OP(10), OP(11), OP(10), OP(11), OP(10), OP(11))
 #define R16(B) B B B B B B B B B B B B B B B B
 
-#define CLOB "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "vcc", "s10", "s11"
+#define CLOB "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "vcc", "scc", "s10", "s11"
 
 #define DEFK(NAME, BODY128)                                                                                  \
     __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long* out, int iters)                     \
@@ -193,7 +194,7 @@ int main(int argc, char** argv)
         {"add+s_nop ind", k_add_nop_ind}, {"pk_min+s_nop ind", k_pk_min_nop_ind},
         {"mix 6 fast 2 slow ind", k_mix_f6s2_ind}, {"mix 6 fast(dep) 2 slow", k_mix_f6s2_dep},
         {"mix 6 fast 2 slow(b) ind", k_mix_f6s2b_ind}, {"mix 4 fast 4 slow ind", k_mix_f4s4_ind},
-        {"mix slow pair + 6 fast", k_mix_s2f6_ind}, {"mix 6 fast 2 salu", k_mix_f6salu2_ind},
+        {"mix slow pair + 6 fast", k_mix_s2f6_ind},
         {"fast opcodes mixed ind", k_fastmix_ind}, {"fast opcodes mixed dep", k_fastmix_dep},
         {"slow 1 in 32", k_slow1in32}, {"slow 1 in 16", k_slow1in16}, {"slow 1 in 8 (pk_min)", k_slow1in8},
         {"slow 1 in 8 (add_dpp)", k_dpp1in8}, {"slow 1 in 8 (bfi)", k_bfi1in8},
@@ -202,6 +203,7 @@ int main(int argc, char** argv)
         E3(min_u16) E3(sub_u16) E3(lshl_b16) E3(not_b32) E3(xor_b32) E3(ashr) E3(subrev) E3(max_i16) E3(cndmask_vcc)
         E3(mul_lo_u16) E3(add_f16) E3(mul_f32) E3(fmac_f32) E3(max_f32) E3(cvt_f32_ubyte0) E3(add_literal) E3(and_literal)
         E3(add_e64_sgpr) E3(add_sgpr)
+        {"mix 6 fast 2 salu", k_mix_f6salu2_ind},
     };
     // optional arguments: substrings of the names to run
     hipDeviceProp_t prop;
@@ -220,13 +222,12 @@ int main(int argc, char** argv)
         bool want = argc <= 1;
         for (int i = 1; i < argc; ++i) want = want || strstr(e.name, argv[i]);
         if (!want) continue;
+        const auto t_entry = std::chrono::steady_clock::now();
         printf("%-28s", e.name);
         for (int wps : {1, 2, 3, 4, 8}) {
             // waves per CU = wps * 4 SIMDs; one block per CU up to 1024 threads, two blocks per CU for 8
             const int blocks = wps == 8 ? 2 * cus : cus;
             const int threads = wps == 8 ? 1024 : wps * 256;
-            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, 10);
-            (void)hipDeviceSynchronize();
             hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, iters);
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(host.data(), out, (size_t)blocks * threads * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -237,6 +238,7 @@ int main(int argc, char** argv)
             const double wave_cycles = (double)cyc[cyc.size() / 2];
             printf(" %7.2f", wave_cycles / ((double)iters * per_iter) / wps);
         }
+        if (getenv("UB_WALL")) printf("  [%.2f s]", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count());
         printf("\n");
         fflush(stdout);
     }
