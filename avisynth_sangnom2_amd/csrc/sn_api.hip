@@ -356,8 +356,11 @@ static int create_impl(const sn_config* cfg, Context* c)
         const int nw = cfg->bytes_per_sample == 2 ? sn::fused_u16_waves(cfg->width) : sn::fused_v3_waves(cfg->width);
         const int round = 256 * (8 / nw);
         if (c->fslots > round) c->fslots -= c->fslots % round;
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
             SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->fslots));
+            // cells outside the hand-off's dependency cone are never written: zero, so that the debug read-back is defined
+            SN_HIP(c, hipMemsetAsync(c->fpool[i], 0, (size_t)c->fpool_frame_bytes * c->fslots, c->stream));
+        }
     }
     SN_HIP(c, hipStreamSynchronize(c->stream));
     return SN_OK;
@@ -526,6 +529,10 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
                 fp.sweep_w = c->cfg.width;
                 fp.frame_stride = c->fpool_frame_bytes;
                 fp.pool_rows = c->fpool_rows;
+                fp.cone_w = c->plane_w(1);  // the hand-off's dependency cone (sn_fused_v3_common.h, Args)
+                fp.cone_nr = nr_c;
+                fp.cone_in = p == 1 ? 6 : 0;
+                fp.cone_out = p == 0 ? 6 : 0;
                 if (p == 0) {
                     fp.mode = 1;
                     fp.pool_out = c->fpool[0] + (int64_t)slot0 * c->fpool_frame_bytes;

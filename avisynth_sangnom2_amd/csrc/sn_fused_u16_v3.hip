@@ -165,9 +165,10 @@ struct PoolIO {
     int v_out;  // slot this lane writes
     int row_stride, buf_stride;
 
-    __device__ __forceinline__ u32x4 issue(int b, int row, bool row_ok) const
+    // va: v_a, or kOutOfRange where the row does not exist or the lane lies outside the dependency cone (Args::cone_*)
+    __device__ __forceinline__ u32x4 issue(int b, int row, int va) const
     {
-        return __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_a : kOutOfRange, b * buf_stride + row * row_stride, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rin, va, b * buf_stride + row * row_stride, 0);
     }
     __device__ __forceinline__ void finish(const u32x4& d, unsigned (&P)[PXL]) const
     {
@@ -189,7 +190,7 @@ struct PoolIO {
 
 struct RowCtx {
     int r;
-    bool next_ok;
+    int vin;  // kChroma: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
     int vout;
 };
 
@@ -293,11 +294,11 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 #pragma unroll
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
     u32x4 st0{}, st1{};
-    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.next_ok);
+    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.vin);
     auto run = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
         if constexpr (MODE == kChroma) {
-            if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.next_ok);
+            if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.vin);
         }
         if constexpr (B < reg_buffers(MODE)) {
             buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st0);
@@ -472,12 +473,21 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     unpack(L1, q1, role);
     parked.park(tid, L0);
 
+    // Does this lane's slot of pool row q matter (Args::cone_*)?  Its first column is 8 * lane + 480 * wave.
+    auto in_cone = [&](int q, int extra) -> bool {
+        const int lim = a.cone_w + 3 * (a.cone_nr - q + 2) + extra;
+        const int cols = lim < a.w ? lim : a.w;
+        const int xa = (lane << 3) + wave * (kInner * PXL);
+        return xa < cols && (q > a.cone_nr || xa + PXL > a.cone_w);
+    };
+    const bool first_in = MODE == kChroma && a.rows_in >= 1 && in_cone(1, a.cone_in);
+
     // A[1] = O[0] + P[1] = P[1]
     unsigned A[RB][PXL];
     auto init_A = [&](auto buf, unsigned (&Ab)[PXL]) {
         constexpr int B = decltype(buf)::value;
         if constexpr (MODE == kChroma) {
-            io.finish(io.issue(B, 1, a.rows_in >= 1), Ab);
+            io.finish(io.issue(B, 1, first_in ? io.v_a : kOutOfRange), Ab);
             if (nr > 0) {
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) Ab[j] = role.inside ? cost<B>(L0, L1, j) : Ab[j];
@@ -563,8 +573,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         }
         RowCtx rc;
         rc.r = r;
-        rc.next_ok = r + 1 <= a.rows_in;
-        rc.vout = (has_pools(MODE) && r <= a.rows_out) ? io.v_out : kOutOfRange;
+        rc.vin = rc.vout = kOutOfRange;
+        if constexpr (MODE == kChroma) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+        if constexpr (has_pools(MODE)) rc.vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
         pending = row_step<MODE, S1, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c
         if (r < sweep && r % K == 0) {
@@ -689,6 +700,10 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.rows_out = pool->pool_out ? pool->rows_out : 0;
     a.region_w = p.w;
     a.sweep_rows = pool->sweep_rows;
+    a.cone_w = pool->cone_w;
+    a.cone_nr = pool->cone_nr;
+    a.cone_in = pool->cone_in;
+    a.cone_out = pool->cone_out;
     if (pool->mode == v3c::kLumaSpill) return w16::launch_mode<v3c::kLumaSpill>(st, a, nframes);
     if (pool->mode == v3c::kPadded) return w16::launch_mode<v3c::kPadded>(st, a, nframes);
     return w16::launch_mode<v3c::kChroma>(st, a, nframes);

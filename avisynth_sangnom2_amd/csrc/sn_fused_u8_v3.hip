@@ -194,62 +194,64 @@ __device__ __forceinline__ void box7(const unsigned (&S)[PXL], unsigned (&Bx)[PX
     for (int j = 0; j + 1 < PXL; ++j) Bx[j + 1] = Bx[j] - X(j - 3) + X(j + 4);
 }
 
-// Access to the scratch pools of the chroma coupling (see Mode).
+// Access to the scratch pools of the chroma coupling (see Mode).  A thread's slot of a pool row is two 8-byte chunks:
+// chunk 0 = the 8 smoothed bytes of its low-half strip, chunk 1 = those of its high-half strip.  A lane fetches each
+// half from the chunk of the thread that OWNS those columns (ghost lanes: the neighbouring wave's seam lanes; at the
+// wrap seam between strip NW-1 and strip NW the owner's columns sit in the OTHER half), so nothing is shuffled after
+// the load, and each half is stored / fetched only where the dependency cone (Args::cone_*) needs it.
 struct PoolIO {
     __amdgpu_buffer_rsrc_t rin, rout;
-    int v_a, v_b;        // voffset of the slot this lane reads (own or owner's), of the second source
-    unsigned keep_mask;  // halves taken from slot a; the others come from slot b with halves swapped
-    bool need_b;         // wave-uniform: some lane of this wave needs slot b
-    int v_out;           // voffset of the slot this lane writes
+    int v_lo, v_hi;          // voffsets of the chunks this lane's low / high half reads
+    int v_out_lo, v_out_hi;  // ... writes (out of range for ghost and dead halves)
     int row_stride, buf_stride;
 
     struct RawPair {
-        u32x4 a, b;
+        u32x2 lo, hi;
     };
-    // issue the load(s) of buffer `b`, pool row `row` (row_ok == false: the row does not exist -> zero)
-    __device__ __forceinline__ RawPair issue(int b, int row, bool row_ok) const
+    // issue the loads of buffer `b`, pool row `row`; vlo / vhi: v_lo / v_hi, or kOutOfRange where the row does not exist
+    // or the half lies outside the cone (the load then returns zero)
+    __device__ __forceinline__ RawPair issue(int b, int row, int vlo, int vhi) const
     {
         const int soff = b * buf_stride + row * row_stride;
         RawPair q;
-        q.a = __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_a : kOutOfRange, soff, 0);
-        q.b = q.a;
-        if (need_b) q.b = __builtin_amdgcn_raw_buffer_load_b128(rin, row_ok ? v_b : kOutOfRange, soff, 0);
+        q.lo = __builtin_amdgcn_raw_buffer_load_b64(rin, vlo, soff, 0);
+        q.hi = __builtin_amdgcn_raw_buffer_load_b64(rin, vhi, soff, 0);
         return q;
     }
     // ... and turn them into packed pairs
     __device__ __forceinline__ void finish(const RawPair& q, unsigned (&P)[PXL]) const
     {
-        u32x4 d = q.a;
-        if (need_b) {
-            d.x = bfi(keep_mask, d.x, __builtin_amdgcn_alignbit(q.b.x, q.b.x, 16));
-            d.y = bfi(keep_mask, d.y, __builtin_amdgcn_alignbit(q.b.y, q.b.y, 16));
-            d.z = bfi(keep_mask, d.z, __builtin_amdgcn_alignbit(q.b.z, q.b.z, 16));
-            d.w = bfi(keep_mask, d.w, __builtin_amdgcn_alignbit(q.b.w, q.b.w, 16));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            P[k] = pair_byte(q.hi.x, q.lo.x, k);
+            P[4 + k] = pair_byte(q.hi.y, q.lo.y, k);
         }
-        P[0] = d.x & kByte; P[1] = (d.x >> 8) & kByte;
-        P[2] = d.y & kByte; P[3] = (d.y >> 8) & kByte;
-        P[4] = d.z & kByte; P[5] = (d.z >> 8) & kByte;
-        P[6] = d.w & kByte; P[7] = (d.w >> 8) & kByte;
     }
-    __device__ __forceinline__ void load(int b, int row, bool row_ok, unsigned (&P)[PXL]) const
+    __device__ __forceinline__ void load(int b, int row, int vlo, int vhi, unsigned (&P)[PXL]) const
     {
-        finish(issue(b, row, row_ok), P);
+        finish(issue(b, row, vlo, vhi), P);
     }
-    // vout: v_out, or kOutOfRange for rows that are not kept (the store is then dropped: no branch)
-    __device__ __forceinline__ void store(int b, int row, int vout, const unsigned (&O)[PXL]) const
+    // vlo / vhi: v_out_lo / v_out_hi, or kOutOfRange for what is not kept (the store is then dropped: no branch)
+    __device__ __forceinline__ void store(int b, int row, int vlo, int vhi, const unsigned (&O)[PXL]) const
     {
-        u32x4 d;
-        d.x = O[0] | (O[1] << 8);
-        d.y = O[2] | (O[3] << 8);
-        d.z = O[4] | (O[5] << 8);
-        d.w = O[6] | (O[7] << 8);
-        store_b128(d, rout, vout, b * buf_stride + row * row_stride);
+        // O[j] = low-strip byte | high-strip byte << 16  ->  four bytes per dword and strip
+        const unsigned t01 = __builtin_amdgcn_perm(O[1], O[0], 0x06020400u), t23 = __builtin_amdgcn_perm(O[3], O[2], 0x06020400u);
+        const unsigned t45 = __builtin_amdgcn_perm(O[5], O[4], 0x06020400u), t67 = __builtin_amdgcn_perm(O[7], O[6], 0x06020400u);
+        u32x2 lo, hi;
+        lo.x = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+        lo.y = __builtin_amdgcn_perm(t67, t45, 0x05040100u);
+        hi.x = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+        hi.y = __builtin_amdgcn_perm(t67, t45, 0x07060302u);
+        const int soff = b * buf_stride + row * row_stride;
+        __builtin_amdgcn_raw_buffer_store_b64(lo, rout, vlo, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(hi, rout, vhi, soff, 0);
     }
 };
 
 struct RowCtx {  // what a row needs besides the lines
     int r;          // pool row being smoothed
-    bool next_ok;   // kChroma: row r + 1 exists in pool_in
+    int vin_lo, vin_hi;  // kChroma: voffsets of the loads of row r + 1 (out of range: row missing or outside the cone)
+    int vout_hi;         // like vout (= the low half's chunk), for the high half's chunk
     int vout;       // voffset for this row's O in pool_out (out of range: not kept)
 };
 
@@ -258,11 +260,16 @@ struct RowCtx {  // what a row needs besides the lines
 template <int BUF, int MODE, bool S1>
 __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
                                             const LaneRole& role, const PoolIO& io, const RowCtx& rc,
-                                            const PoolIO::RawPair& stale)
+                                            PoolIO::RawPair& stale)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
     if constexpr (MODE == kChroma) {
         io.finish(stale, D);
+        // the next buffer's stale row is fetched into the registers this one has just left (one buffer step of lead;
+        // the fence keeps the compiler from hoisting the load above the unpacking, which would double the registers
+        // in flight -- this mode lives at the register limit, and a spill reload waits for every load before it)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BUF + 1 < kBuffers) stale = io.issue(BUF + 1, rc.r + 1, rc.vin_lo, rc.vin_hi);
         if constexpr (S1) {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) D[j] = bfi(role.inside_mask, cost<BUF>(n, nn, j), D[j]);
@@ -297,7 +304,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             kmin[j] = pk_min(kmin[j], key);
         }
     }
-    if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
+    if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
 }
 
 struct Out {
@@ -311,7 +318,7 @@ struct Out {
 // Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
 // The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
 // in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
-__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 6; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 3 : 6; }
 template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
@@ -368,13 +375,10 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
     // kChroma: the previous pass's row r+1 is fetched one buffer ahead of its use (HBM latency), and the
     // scheduler is kept from hoisting all nine fetches (their registers would spill).
-    PoolIO::RawPair st0{}, st1{};
-    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.next_ok);
+    PoolIO::RawPair st0{};
+    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.vin_lo, rc.vin_hi);
     auto run = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
-        if constexpr (MODE == kChroma) {
-            if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.next_ok);
-        }
         if constexpr (B < reg_buffers(MODE)) {
             buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st0);
         } else {
@@ -383,7 +387,6 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
             buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st0);
             store_A(pk, tid, B, t);
         }
-        if constexpr (MODE == kChroma) st0 = st1;
     };
     run(std::integral_constant<int, 0>{});
     run(std::integral_constant<int, 1>{});
@@ -441,18 +444,22 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 //                                          half of wave 0 (strip NW) <- wave NW-1 lanes 60, 61 lo half (strip NW-1)
 //   right ghosts (lanes 62, 63) of wave W: both halves <- wave W+1 lanes 2, 3 (same half), except that the lo
 //                                          half of wave NW-1 (strip NW-1) <- wave 0 lanes 2, 3 hi half (strip NW)
-template <int NW>
-struct Mailbox {  // [parity][wave 0..NW][side][slot][72][2 halves] 16-bit entries in dynamic LDS (entry NW is unused)
+// The pool-coupled modes park six buffers' state in LDS and have room for ONE copy of the mailbox only: there a second
+// barrier (before publishing) makes sure every wave has taken the previous refresh out of it.  The other modes keep two
+// copies, alternating, and meet once per refresh.
+__host__ __device__ constexpr int mailbox_copies(int mode) { return has_pools(mode) ? 1 : 2; }
+template <int NW, int COPIES>
+struct Mailbox {  // [copy][wave 0..NW-1][side][slot][72][2 halves] 16-bit entries in dynamic LDS
     unsigned short* h;
     __device__ __forceinline__ unsigned short* at(int par, int wave, int side, int slot) const
     {
-        return h + ((((par * (NW + 1) + wave) * 2 + side) * GH + slot) * (kBuffers * PXL)) * 2;
+        return h + (((((COPIES > 1 ? par : 0) * NW + wave) * 2 + side) * GH + slot) * (kBuffers * PXL)) * 2;
     }
 };
 
 __host__ __device__ constexpr int lds_bytes(int nw, int mode)
 {
-    return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
+    return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + mailbox_copies(mode) * nw * 2 * GH * kBuffers * PXL * 4;
 }
 
 template <int NW, int MODE>
@@ -469,7 +476,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     Parked<NW * 64, kRegBuffers> parked;
     parked.v = reinterpret_cast<uint4*>(lds_raw + sub * lds_bytes(NW, MODE));
     parked.a = parked.v + 6 * NW * 64;
-    Mailbox<NW> mb;
+    Mailbox<NW, mailbox_copies(MODE)> mb;
     mb.h = reinterpret_cast<unsigned short*>(parked.a + (kBuffers - kRegBuffers) * 2 * NW * 64);
     const int wave = tid >> 6;
     const int lane = tid & 63;
@@ -566,24 +573,32 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
                                                        a.pool_in ? pool_bytes : 0, 0x00020000);
         io.rout = __builtin_amdgcn_make_buffer_rsrc(a.pool_out ? a.pool_out + (int64_t)f * a.pool_frame_stride : nullptr, 0,
                                                     a.pool_out ? pool_bytes : 0, 0x00020000);
-        // the slot a lane reads: its own, or -- for ghost lanes -- the slot of the thread that owns
-        // those columns (lanes 60, 61 of the previous wave / lanes 2, 3 of the next one).  The two
-        // strips of a wave meet their neighbours in the same thread, except at the seam between
-        // strip NW-1 and strip NW, where the partner sits in the other half of another wave.
-        int ta = tid, tb = tid;
-        io.keep_mask = 0xffffffffu;
+        // whose chunks a lane reads: its own, or -- for ghost lanes -- those of the thread that owns the columns (lanes
+        // 60, 61 of the previous wave / lanes 2, 3 of the next one).  The two strips of a wave meet their neighbours in
+        // the same thread, except at the seam between strip NW-1 and strip NW, where the partner's columns sit in
+        // the other half of another wave.
+        int t_lo = tid, t_hi = tid, c_lo = 0, c_hi = 1;
         if (lane < GH) {
-            if (wave > 0) ta = (wave - 1) * 64 + (64 - 2 * GH) + lane;
-            else { tb = (NW - 1) * 64 + (64 - 2 * GH) + lane; io.keep_mask = kLo; }  // hi half <- strip NW-1 (a lo half)
+            if (wave > 0) t_lo = t_hi = (wave - 1) * 64 + (64 - 2 * GH) + lane;
+            else { t_hi = (NW - 1) * 64 + (64 - 2 * GH) + lane; c_hi = 0; }  // hi half <- strip NW-1 (a low half)
         } else if (lane >= 64 - GH) {
-            if (wave < NW - 1) ta = (wave + 1) * 64 + GH + (lane - (64 - GH));
-            else { tb = GH + (lane - (64 - GH)); io.keep_mask = kHi; }               // lo half <- strip NW (a hi half)
+            if (wave < NW - 1) t_lo = t_hi = (wave + 1) * 64 + GH + (lane - (64 - GH));
+            else { t_lo = GH + (lane - (64 - GH)); c_lo = 1; }               // lo half <- strip NW (a high half)
         }
-        io.v_a = ta * 16;
-        io.v_b = tb * 16;
-        io.need_b = __builtin_amdgcn_readfirstlane(wave == 0 || wave == NW - 1) != 0;
-        io.v_out = (real[0] || real[1]) ? tid * 16 : kOutOfRange;
+        io.v_lo = t_lo * 16 + c_lo * 8;
+        io.v_hi = t_hi * 16 + c_hi * 8;
+        io.v_out_lo = real[0] ? tid * 16 : kOutOfRange;
+        io.v_out_hi = real[1] ? tid * 16 + 8 : kOutOfRange;
     }
+
+    // Does a half of this lane matter in pool row q (Args::cone_*)?  Column of the low half: 8 * lane + 480 * wave, the
+    // high half lies 480 * NW further right (strips in column order); recomputed per row from the lane id, not kept.
+    auto in_cone = [&](int q, int extra, int h) -> bool {
+        const int lim = a.cone_w + 3 * (a.cone_nr - q + 2) + extra;
+        const int cols = lim < a.w ? lim : a.w;
+        const int x = (lane << 3) + (wave + h * NW) * (kInner * PXL);
+        return x < cols && (q > a.cone_nr || x + PXL > a.cone_w);
+    };
 
     const int nk = a.nk;
     const int nr = nk - 1;
@@ -603,10 +618,12 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // A[1] = O[0] + P[1] = P[1] (pool row 0 is never written: zero); P[1] = stage-1 costs of the first
     // line pair, and outside the chroma region (kChroma) what the previous pass left in row 1
     unsigned A[kRegBuffers][PXL];
+    const bool first_lo = MODE == kChroma && a.rows_in >= 1 && in_cone(1, a.cone_in, 0);
+    const bool first_hi = MODE == kChroma && a.rows_in >= 1 && in_cone(1, a.cone_in, 1);
     auto init_A = [&](auto buf, unsigned (&Ab)[PXL]) {
         constexpr int B = decltype(buf)::value;
         if constexpr (MODE == kChroma) {
-            io.load(B, 1, a.rows_in >= 1, Ab);
+            io.load(B, 1, first_lo ? io.v_lo : kOutOfRange, first_hi ? io.v_hi : kOutOfRange, Ab);
             if (nr > 0) {
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) Ab[j] = bfi(role.inside_mask, cost<B>(L0, L1, j), Ab[j]);
@@ -655,7 +672,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     const unsigned ghost_mask = (ghost[0] && live[0] ? kLo : 0u) | (ghost[1] && live[1] ? kHi : 0u);
     const int slot = recv_left ? lane : recv_right ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
 
-    Out pending{};
     // One pool row r: n = K[r], nn = K[r+1] (S1: the pair exists), c = K[r-1] parked (S3: the row has an
     // interpolated line).
     TurnTaking turns;
@@ -669,10 +685,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             unpack(nn, qn, role);  // waits for the line prefetched one row ago
             keep(dst_keep, qn);
             dst_keep += dst_step;
-        }
-        if (r > 1 && r <= nr) {
-            put(out_row, pending);
-            out_row += dst_step;
         }
         if constexpr (HAS_NEXT) {
             if (r + 2 <= nr) qnext = load_raw(src_next);  // prefetch K[r+2]
@@ -700,12 +712,26 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         }
         RowCtx rc;
         rc.r = r;
-        rc.next_ok = r + 1 <= a.rows_in;
-        rc.vout = (has_pools(MODE) && r <= a.rows_out) ? io.v_out : kOutOfRange;
-        pending = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
+        rc.vin_lo = rc.vin_hi = rc.vout = rc.vout_hi = kOutOfRange;
+        if constexpr (MODE == kChroma) {
+            const bool row_in = r + 1 <= a.rows_in;
+            rc.vin_lo = (row_in && in_cone(r + 1, a.cone_in, 0)) ? io.v_lo : kOutOfRange;
+            rc.vin_hi = (row_in && in_cone(r + 1, a.cone_in, 1)) ? io.v_hi : kOutOfRange;
+        }
+        if constexpr (has_pools(MODE)) {
+            const bool row_out = r <= a.rows_out;
+            rc.vout = (row_out && in_cone(r, a.cone_out, 0)) ? io.v_out_lo : kOutOfRange;
+            rc.vout_hi = (row_out && in_cone(r, a.cone_out, 1)) ? io.v_out_hi : kOutOfRange;
+        }
+        const Out o = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
+        if constexpr (S3) {  // stored at once: nothing is carried into the next row
+            put(out_row, o);
+            out_row += dst_step;
+        }
         if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
         if (r < sweep) {
             if (r % K == 0) {
+                if constexpr (mailbox_copies(MODE) == 1) __syncthreads();  // the previous refresh has been taken out
                 const int wpar = ((r + 1) / K) & 1;
                 if (pub_right || pub_left) {
                     // Inside the plane both halves of a seam register go to the same ghost lane of the neighbouring
@@ -761,10 +787,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         step(r, L1, L0, T{}, T{});
         L1 = L0;
     }
-    if (nr >= 1) {
-        step(nr, L1, L0, F{}, T{});
-        put(out_row, pending);
-    }
+    if (nr >= 1) step(nr, L1, L0, F{}, T{});
     if constexpr (MODE == kChroma) {
         for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
     }
@@ -791,12 +814,14 @@ int fused_v3_waves(int sweep_w) { return (v3::virtual_waves_for(sweep_w / v3::PX
 // bytes of one scratch pool of one frame: [9][rows][threads][16]
 int64_t fused_v3_pool_bytes(int sweep_w, int rows) { return (int64_t)kBuffers * rows * fused_v3_waves(sweep_w) * 64 * 16; }
 
-// Slot of thread t, dword k: bytes 0, 1 = columns 2k, 2k+1 of the strip in the low halves (strip `wave`),
-// bytes 2, 3 = the same of the strip in the high halves (strip `wave + nw`), as PoolIO::store packs them.
+// Slot of thread t: bytes 0..7 = the eight columns of its strip in the low halves (strip `wave`), bytes 8..15 = those of the
+// strip in the high halves (strip `wave + nw`), as PoolIO::store packs them.  Cells outside the dependency cone are
+// never written; `out` keeps what the caller put there.
 void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* out)
 {
     using namespace v3c;
     const int nl = sweep_w / PXL, nvw = v3::virtual_waves_for(nl), nw = (nvw + 1) / 2, nt = nw * 64;
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(raw);
     for (int64_t br = 0; br < (int64_t)kBuffers * rows; ++br)
         for (int t = 0; t < nt; ++t)
             for (int h = 0; h < 2; ++h) {
@@ -804,9 +829,9 @@ void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* o
                 const int gl = vw == 0 ? lane : kFirst + kInner * (vw - 1) + (lane - GH);
                 const bool ghost = vw == 0 ? (nvw > 1 && lane >= 64 - GH) : (lane < GH || (lane >= 64 - GH && vw < nvw - 1));
                 if (vw >= nvw || ghost || gl >= nl) continue;
-                const uint32_t* d = raw + (br * nt + t) * 4;
+                const uint8_t* d = bytes + (br * nt + t) * 16 + h * 8;
                 uint8_t* o = out + br * sweep_w + gl * PXL;
-                for (int k = 0; k < 4; ++k) { o[2 * k] = (uint8_t)(d[k] >> (16 * h)); o[2 * k + 1] = (uint8_t)(d[k] >> (16 * h + 8)); }
+                for (int k = 0; k < PXL; ++k) o[k] = d[k];
             }
 }
 
@@ -855,7 +880,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.nw = (a.nvw + 1) / 2;
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
-    a.dbg = 0;
+
     a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
     a.nframes = nframes;
     if (!pool) return launch_mode<v3::kPlain>(st, a, nframes);
@@ -867,6 +892,10 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.rows_out = pool->pool_out ? pool->rows_out : 0;
     a.region_w = p.w;
     a.sweep_rows = pool->sweep_rows;
+    a.cone_w = pool->cone_w;
+    a.cone_nr = pool->cone_nr;
+    a.cone_in = pool->cone_in;
+    a.cone_out = pool->cone_out;
     if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
     if (pool->mode == v3::kPadded) return launch_mode<v3::kPadded>(st, a, nframes);
     return launch_mode<v3::kChroma>(st, a, nframes);

@@ -38,7 +38,13 @@ struct Args {
     int32_t nw;      // physical waves
     int32_t src_bytes;  // bytes of one source plane (buffer descriptor range)
     int32_t dst_bytes;  // bytes of one destination plane
-    int32_t dbg;        // unused (kept for layout)
+    // Dependency cone of the pool coupling.  A hand-off cell (pool row q, column x) can reach a chroma output only if
+    // x < cone_w + 3 * (cone_nr - q + 2) (+6 for the luma -> U hand-off, whose cells act through U's sweep): stage 2
+    // spreads 3 columns per row and the chroma region ends at column cone_w, row cone_nr.  Inside the region
+    // (x < cone_w) a cell matters only below it (q > cone_nr).  Lanes whose columns lie outside neither store nor
+    // load their slot (out-of-range voffset: no branch, no HBM traffic).
+    int32_t cone_w, cone_nr;   // chroma width, chroma nr = interpolated lines
+    int32_t cone_in, cone_out; // extra columns of the loads (U: 6, V: 0) / of the stores (luma: 6, U: 0)
     // pool coupling for subsampled chroma (modes kLumaSpill / kChroma, see below)
     const uint8_t* pool_in;   // smoothed buffers left by the previous pass (kChroma)
     uint8_t* pool_out;        // where this pass leaves its smoothed buffers (kLumaSpill, first kChroma pass)

@@ -67,6 +67,8 @@ struct FusedPool {
     int pool_rows;           // rows per pool buffer
     int rows_in, rows_out;   // valid rows in pool_in / rows to write to pool_out
     int sweep_rows;          // chroma: pool rows to sweep
+    int cone_w, cone_nr;     // the chroma plane's width and interpolated lines (dependency cone of the hand-off, Args)
+    int cone_in, cone_out;   // extra columns: what this pass loads / stores beyond the final pass's cone
 };
 int fused_v3_waves(int sweep_w);
 int64_t fused_v3_pool_bytes(int sweep_w, int rows);

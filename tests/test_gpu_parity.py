@@ -376,11 +376,22 @@ def test_fused_420_hand_off_rows_match_the_shared_pool(hip_lib, fmt, w, h):
         rows = flt.info().coupled_rows
         nr_c, bh = h // 4 - 1, (h + 1) // 2
         assert rows == min(nr_c + 2, bh - 1) + 1
-        for which, last in ((0, rows - 1), (1, min(nr_c + 1, bh - 1))):
+        # Only the cells inside the dependency cone are handed on: (row q, column x) can reach a chroma output iff
+        # x < w_c + 3 * (nr_c - q + 2) (+6 for what U needs from luma), and inside the chroma region (x < w_c) only
+        # the rows below it matter (sn_fused_v3_common.h, Args::cone_*).  What lies outside is never written.
+        w_c = w // 2
+        for which, last, extra in ((0, rows - 1, 6), (1, min(nr_c + 1, bh - 1), 0)):
             got = flt.read_coupled_rows(which)[:, 1:last + 1].astype(np.int64)
             exp = want[which][:, 1:last + 1, :w]
-            bad = np.argwhere(got != exp)
+            q = np.arange(1, last + 1)[:, None]
+            x = np.arange(w)[None, :]
+            cone = (x < w_c + 3 * (nr_c - q + 2) + extra) & ((x >= w_c) | (q > nr_c))
+            assert cone.any()
+            bad = np.argwhere((got != exp) & cone[None])
             assert len(bad) == 0, f"hand-off {which}: {len(bad)} samples differ, first (buffer,row-1,x) {bad[:4].tolist()}"
+            if h >= 256:  # the trimming is real: far outside the cone nothing was stored (pools start zero-filled)
+                far = (x >= w_c + 3 * (nr_c - q + 2) + extra + 16) & (q <= nr_c)
+                assert far.any() and not got[:, far].any()
 
 
 @pytest.mark.parametrize("fmt,mode", [("YUV420P8", "fused"), ("YUV420P16", "fused"), ("YUV420P8", "pool"), ("Y16", "pool")])
