@@ -252,6 +252,7 @@ struct RowCtx {  // what a row needs besides the lines
     int r;          // pool row being smoothed
     int vin_lo, vin_hi;  // kChroma: voffsets of the loads of row r + 1 (out of range: row missing or outside the cone)
     int vout_hi;         // like vout (= the low half's chunk), for the high half's chunk
+    bool any_out;        // wave-uniform: some lane of this wave stores in this row
     int vout;       // voffset for this row's O in pool_out (out of range: not kept)
 };
 
@@ -265,11 +266,12 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
     if constexpr (MODE == kChroma) {
         io.finish(stale, D);
-        // the next buffer's stale row is fetched into the registers this one has just left (one buffer step of lead;
-        // the fence keeps the compiler from hoisting the load above the unpacking, which would double the registers
-        // in flight -- this mode lives at the register limit, and a spill reload waits for every load before it)
+        // the stale row of the buffer after next is fetched into the registers this one has just left (two buffer steps
+        // of lead, two loads in flight; the fence keeps the compiler from hoisting the load above the unpacking, which
+        // would add registers in flight -- this mode lives at the register limit, and a spill reload waits for every
+        // load before it)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (BUF + 1 < kBuffers) stale = io.issue(BUF + 1, rc.r + 1, rc.vin_lo, rc.vin_hi);
+        if constexpr (BUF + 2 < kBuffers) stale = io.issue(BUF + 2, rc.r + 1, rc.vin_lo, rc.vin_hi);
         if constexpr (S1) {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) D[j] = bfi(role.inside_mask, cost<BUF>(n, nn, j), D[j]);
@@ -304,7 +306,11 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             kmin[j] = pk_min(kmin[j], key);
         }
     }
-    if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
+    if constexpr (has_pools(MODE)) {
+        // the luma sweep skips the packing where no lane of the wave stores (rows past the hand-off, waves outside
+        // the cone); the chroma sweep cannot afford the branch (registers) and lets the range check drop the stores
+        if (MODE == kChroma || rc.any_out) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
+    }
 }
 
 struct Out {
@@ -375,16 +381,20 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
     // kChroma: the previous pass's row r+1 is fetched one buffer ahead of its use (HBM latency), and the
     // scheduler is kept from hoisting all nine fetches (their registers would spill).
-    PoolIO::RawPair st0{};
-    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.vin_lo, rc.vin_hi);
+    PoolIO::RawPair st0{}, st1{};  // even / odd buffers' stale rows in flight
+    if constexpr (MODE == kChroma) {
+        st0 = io.issue(0, rc.r + 1, rc.vin_lo, rc.vin_hi);
+        st1 = io.issue(1, rc.r + 1, rc.vin_lo, rc.vin_hi);
+    }
     auto run = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
+        PoolIO::RawPair& st = (B & 1) ? st1 : st0;
         if constexpr (B < reg_buffers(MODE)) {
-            buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st0);
+            buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st);
         } else {
             unsigned t[PXL];
             load_A(pk, tid, B, t);
-            buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st0);
+            buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st);
             store_A(pk, tid, B, t);
         }
     };
@@ -713,6 +723,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         RowCtx rc;
         rc.r = r;
         rc.vin_lo = rc.vin_hi = rc.vout = rc.vout_hi = kOutOfRange;
+        rc.any_out = false;
         if constexpr (MODE == kChroma) {
             const bool row_in = r + 1 <= a.rows_in;
             rc.vin_lo = (row_in && in_cone(r + 1, a.cone_in, 0)) ? io.v_lo : kOutOfRange;
@@ -722,6 +733,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             const bool row_out = r <= a.rows_out;
             rc.vout = (row_out && in_cone(r, a.cone_out, 0)) ? io.v_out_lo : kOutOfRange;
             rc.vout_hi = (row_out && in_cone(r, a.cone_out, 1)) ? io.v_out_hi : kOutOfRange;
+            rc.any_out = __builtin_amdgcn_readfirstlane(__any((rc.vout != kOutOfRange) | (rc.vout_hi != kOutOfRange)) ? 1 : 0) != 0;
         }
         const Out o = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S3) {  // stored at once: nothing is carried into the next row
