@@ -242,6 +242,25 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
     if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
 }
 
+// A wave of a chroma sweep whose columns all lie outside the chroma region has no lines, no stage 1 and no stage 3: the
+// cost of the next row is what the previous pass left there, nothing else (see stale_wave_sweep).
+template <int BUF>
+__device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], const u32x4& stale, const LaneRole& role, const PoolIO& io, int r, int vout)
+{
+    unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
+    io.finish(stale, D);
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) S[j] = A[j] + D[j];
+    if (role.edge_wave) box7<true>(S, Bx, role);
+    else box7<false>(S, Bx, role);
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        O[j] = (Bx[j] >> 4) & kVal;  // (sum / 16) wraps to uint16_t, SangNom2.cpp:152
+        A[j] = O[j] + D[j];
+    }
+    io.store(BUF, r, vout, O);
+}
+
 __host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 6; }
 
 template <int NT, int RB>
@@ -458,10 +477,85 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         io.v_out = real ? tid * 16 : kOutOfRange;
     }
 
+    // seam exchange: lanes 60, 61 feed the next wave's left ghosts, lanes 2, 3 the previous wave's right ghosts
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < NW - 1;
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    // Does this lane's slot of pool row q matter (Args::cone_*)?  Its first column is 8 * lane + 480 * wave.
+    auto in_cone = [&](int q, int extra) -> bool {
+        const int lim = a.cone_w + 3 * (a.cone_nr - q + 2) + extra;
+        const int cols = lim < a.w ? lim : a.w;
+        const int xa = (lane << 3) + wave * (kInner * PXL);
+        return xa < cols && (q > a.cone_nr || xa + PXL > a.cone_w);
+    };
+
     const int nk = a.nk;
     const int nr = nk - 1;
     const int sweep = MODE == kChroma ? a.sweep_rows : nr;
     const unsigned thr_key = (unsigned)(a.thr + 1) << 4;
+
+    if constexpr (MODE == kChroma) {
+        // Waves entirely to the right of the chroma region (columns 480 * wave and up; with 4:2:0 the right half of the
+        // workgroup) only re-smooth what the previous pass left: no lines, no costs, no ladder.  All nine buffers' state
+        // stays in registers, the stale rows are fetched a whole row ahead, and the wave LEAVES once every column from
+        // its first one on lies outside the dependency cone (Args::cone_*; the cone only shrinks): its SIMD partner --
+        // a wave of the region, one per SIMD by construction (wave i and i + 4) -- then issues alone.
+        if (wave * (kInner * PXL) >= a.region_w) {
+            const int x_wave = wave * (kInner * PXL);
+            unsigned As[kBuffers][PXL];
+            const int v1 = (a.rows_in >= 1 && in_cone(1, a.cone_in)) ? io.v_a : kOutOfRange;
+            u32x4 sa[kBuffers], sb[kBuffers];
+#pragma unroll
+            for (int b = 0; b < kBuffers; ++b) io.finish(io.issue(b, 1, v1), As[b]);
+            auto fetch = [&](int q, u32x4 (&st)[kBuffers]) {  // pool row q of all nine buffers
+                const int v = (q <= a.rows_in && in_cone(q, a.cone_in)) ? io.v_a : kOutOfRange;
+#pragma unroll
+                for (int b = 0; b < kBuffers; ++b) st[b] = io.issue(b, q, v);
+            };
+            fetch(2, sa);
+            auto stale_row = [&](int r, const u32x4 (&cur)[kBuffers], u32x4 (&nxt)[kBuffers]) -> bool {
+                if (x_wave >= a.cone_w + 3 * (a.cone_nr - (r - 1) + 2) + a.cone_in) return false;  // outside for good
+                fetch(r + 2, nxt);
+                if (r > 1 && (r - 1) % K == 0) {
+                    __syncthreads();
+                    if (recv) {
+                        const unsigned* from = mb.at((r / K) & 1, wave, lane < GH ? 0 : 1, slot);
+#pragma unroll
+                        for (int b = 0; b < kBuffers; ++b)
+#pragma unroll
+                            for (int j = 0; j < PXL; ++j) As[b][j] = from[b * PXL + j];
+                    }
+                }
+                const int vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
+                stale_buffer_step<0>(As[0], cur[0], role, io, r, vout);
+                stale_buffer_step<1>(As[1], cur[1], role, io, r, vout);
+                stale_buffer_step<2>(As[2], cur[2], role, io, r, vout);
+                stale_buffer_step<3>(As[3], cur[3], role, io, r, vout);
+                stale_buffer_step<4>(As[4], cur[4], role, io, r, vout);
+                stale_buffer_step<5>(As[5], cur[5], role, io, r, vout);
+                stale_buffer_step<6>(As[6], cur[6], role, io, r, vout);
+                stale_buffer_step<7>(As[7], cur[7], role, io, r, vout);
+                stale_buffer_step<8>(As[8], cur[8], role, io, r, vout);
+                if (r < sweep && r % K == 0) {
+                    if (pub_right || pub_left) {
+                        unsigned* to = pub_right ? mb.at(((r + 1) / K) & 1, wave + 1, 0, slot) : mb.at(((r + 1) / K) & 1, wave - 1, 1, slot);
+#pragma unroll
+                        for (int b = 0; b < kBuffers; ++b)
+#pragma unroll
+                            for (int j = 0; j < PXL; ++j) to[b * PXL + j] = As[b][j];
+                    }
+                }
+                return true;
+            };
+            for (int r = 1; r <= sweep; r += 2) {
+                if (!stale_row(r, sa, sb)) return;
+                if (r + 1 <= sweep && !stale_row(r + 1, sb, sa)) return;
+            }
+            return;
+        }
+    }
 
     Line L0, L1;
     Raw q0 = load_raw(src_line);
@@ -473,13 +567,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     unpack(L1, q1, role);
     parked.park(tid, L0);
 
-    // Does this lane's slot of pool row q matter (Args::cone_*)?  Its first column is 8 * lane + 480 * wave.
-    auto in_cone = [&](int q, int extra) -> bool {
-        const int lim = a.cone_w + 3 * (a.cone_nr - q + 2) + extra;
-        const int cols = lim < a.w ? lim : a.w;
-        const int xa = (lane << 3) + wave * (kInner * PXL);
-        return xa < cols && (q > a.cone_nr || xa + PXL > a.cone_w);
-    };
     const bool first_in = MODE == kChroma && a.rows_in >= 1 && in_cone(1, a.cone_in);
 
     // A[1] = O[0] + P[1] = P[1]
@@ -525,12 +612,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     int out_row = dst_line + a.dst_pitch;
     Raw qn = nk > 2 ? load_raw(src_next) : q1;
     src_next += src_step;
-
-    // seam exchange: lanes 60, 61 feed the next wave's left ghosts, lanes 2, 3 the previous wave's right ghosts
-    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < NW - 1;
-    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
-    const bool recv = ghost && live;
-    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
 
     Out pending{};
     TurnTaking turns;
