@@ -15,7 +15,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsangnom_oracle.so")
+# SN_ORACLE_LIB: another build of the same sources, e.g. libsangnom_oracle_asan.so (tests/test_oracle.py runs the
+# restatement under AddressSanitizer / UBSan that way, in a child process that preloads the sanitizer runtime)
+_LIB_PATH = os.environ.get("SN_ORACLE_LIB") or os.path.join(_HERE, "libsangnom_oracle.so")
 
 
 def build(force: bool = False) -> str:
@@ -24,7 +26,7 @@ def build(force: bool = False) -> str:
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libsangnom_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, os.path.basename(_LIB_PATH)])
     return _LIB_PATH
 
 

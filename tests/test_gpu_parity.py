@@ -759,3 +759,94 @@ def test_a_stream_sharded_over_logical_ranks_equals_one_context(hip_lib, world, 
     finally:
         for flt in ranks:
             flt.close()
+
+
+# ---- round-2 additions: layout fallback, field orders at full height, non-finite floats ---------------------
+@pytest.mark.parametrize("fmt", ["Y8", "Y16", "Y32", "YUV420P8"])
+def test_misaligned_device_planes_fall_back_to_the_pool_path(hip_lib, fmt):
+    """The fused sweeps need 8-byte aligned plane pointers and pitches (sn_fused_select.hip, fused_layout_ok); anything
+    else is served by the pool path -- same result, `fused_frames` stays 0."""
+    import torch
+    w, h, N = 256, 64, 3
+    clip = clip_format(fmt, w, h)
+    kw = dict(aac=48) if clip.planes == 3 else {}
+    dev = torch.device("cuda:0")
+    frames = make_frames(clip, "noise", N, seed0=31)
+    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
+    B = clip.bytes
+    with SangNom2(clip, max_batch=N, **kw) as flt:
+        assert flt.info().fused_eligible == 1
+        src, dst = [], []
+        for p in range(flt.nplanes):
+            hi, wi = flt.plane_shape_in(p)
+            ho, wo = flt.plane_shape_out(p)
+            # odd pitch (in samples) and a base shifted by one sample: rows start on no 8-byte boundary
+            big = torch.zeros((N, hi, wi + 5), dtype=tdt, device=dev)
+            s = big[:, :, 1:1 + wi]
+            s.copy_(torch.from_numpy(np.stack([fr[p] for fr in frames]).view({1: np.uint8, 2: np.int16, 4: np.float32}[B])))
+            dbig = torch.zeros((N, ho, wo + 3), dtype=tdt, device=dev)
+            src.append(s)
+            dst.append(dbig[:, :, 1:1 + wo])
+            assert (s.data_ptr() % 8) or ((s.stride(1) * B) % 8)
+        torch.cuda.synchronize()
+        flt.process_batch(src, dst)
+        flt.synchronize()
+        assert flt.info().fused_frames == 0 and flt.info().frames == N
+        for f in range(N):
+            want = Oracle(oracle_cfg(clip, **kw)).process(frames[f])
+            for p in range(flt.nplanes):
+                got = dst[p][f].cpu().numpy().view(clip.dtype)
+                assert same(want[p], got), f"{fmt} frame {f} plane {p}"
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 3840, 2160, dict(order=0)), ("Y8", 3840, 2160, dict(order=2, aa=20)),
+                                        ("Y8", 3840, 1080, dict(order=1, dh=True)), ("Y8", 3840, 1080, dict(order=0, dh=True)),
+                                        ("Y16", 3840, 2160, dict(order=2)), ("Y32", 3840, 1080, dict(order=0, dh=True))],
+                         ids=["Y8-order0", "Y8-order2", "Y8-dh", "Y8-dh-order0", "Y16-order2", "Y32-dh-order0"])
+def test_field_orders_and_double_height_at_2160_rows_through_the_sweeps(hip_lib, fmt, w, h, kw):
+    """order 0 / 2 and dh at BASELINE's frame height, fused sweeps: every frame of a small batch (alternating parity for
+    order 0) against the oracle."""
+    import torch
+    clip = clip_format(fmt, w, h)
+    N = 2
+    frames = make_frames(clip, "noise", N, seed0=53)
+    frames[1] = synth.frame(clip, "checker", seed=3)
+    parity = [0, 1]
+    dev = torch.device("cuda:0")
+    npdt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+    with SangNom2(clip, max_batch=N, mode="fused", **kw) as flt:
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames]).view(npdt)).to(dev)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(0), dtype=src[0].dtype, device=dev)]
+        torch.cuda.synchronize()
+        flt.process_batch(src, dst, parity)
+        flt.synchronize()
+        assert flt.info().fused_frames == N
+        for f in range(N):
+            want = Oracle(oracle_cfg(clip, **kw)).process(frames[f], parity=parity[f])
+            assert same(want[0], dst[0][f].cpu().numpy().view(clip.dtype)), f"{fmt} {kw} frame {f}"
+
+
+@pytest.mark.parametrize("mode", ["fused", "pool"])
+def test_non_finite_float_samples_follow_the_reference_ladder(hip_lib, mode):
+    """Float clips may carry infinities and NaNs.  Where a NaN reaches the minimum of the nine buffers the reference takes
+    NO arm of its ladder (every `==` and the `>` are false, src/SangNom2.cpp:204-249) and leaves the pixel of the new
+    frame unwritten -- undefined content, nothing to match.  Everywhere else its result is defined by the `std::min`
+    chain and the ladder, which the oracle restates operation for operation, and the HIP path must agree: bit patterns
+    for numbers, NaN for NaN (x86 and gfx950 give the default NaN different signs)."""
+    clip = clip_format("Y32", 256, 64)
+    rng = np.random.default_rng(4)
+    src = synth.frame(clip, "noise", seed=9)
+    plane = src[0]
+    ys, xs = rng.integers(0, 64, 40), rng.integers(0, 256, 40)
+    vals = np.array([np.inf, -np.inf, np.nan, 3.0e38, -3.0e38], dtype=np.float32)
+    plane[ys, xs] = vals[rng.integers(0, len(vals), 40)]
+    # pixels the reference writes: the same whatever the new frame held before
+    a = Oracle(oracle_cfg(clip)).process(src, dst=[np.zeros((64, 256), np.float32)])[0]
+    b = Oracle(oracle_cfg(clip)).process(src, dst=[np.full((64, 256), 7.0, np.float32)])[0]
+    written = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert written.mean() > 0.7 and not written.all()
+    with SangNom2(clip, mode=mode) as flt:
+        got = flt.get_frame(src)[0]
+    ok = (a.view(np.uint32) == got.view(np.uint32)) | (np.isnan(a) & np.isnan(got))
+    bad = np.argwhere(written & ~ok)
+    assert len(bad) == 0, f"{len(bad)} defined samples differ, first {bad[:4].tolist()}: {a[written & ~ok][:4]} vs {got[written & ~ok][:4]}"

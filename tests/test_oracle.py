@@ -234,3 +234,48 @@ def test_vectorised_port_is_bit_identical_to_the_oracle(w, h, order, aa):
         a, b = o.process(src, parity=f & 1)[0], v.process(src[0], parity=f & 1)
         assert np.array_equal(a, b), f"frame {f}"
         assert np.array_equal(o.pool(), v.pool()), f"pool after frame {f}"
+
+
+_ASAN_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from avisynth_sangnom2_amd import synth
+from oracle.oracle import Config, Oracle
+from oracle.sangnom_numpy import NumpySangNom
+from tests.test_oracle import CROSS
+n = 0
+for kw in CROSS:
+    cfg = Config(**kw)
+    for pattern in ("noise", "checker", "edges"):
+        o, ref = Oracle(cfg), NumpySangNom(**kw)
+        for f in range(2):
+            src = synth.frame(cfg, pattern, seed=f + 1)
+            a, b = o.process(src, parity=f & 1), ref.get_frame(src, parity=f & 1)
+            for p in range(len(a)):
+                x, y = a[p], b[p]
+                if x.dtype == np.float32:
+                    x, y = x.view(np.uint32), y.view(np.uint32)
+                assert np.array_equal(x, y)
+            n += 1
+print("asan-ok", n)
+"""
+
+
+def test_restatement_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The C restatement over the CROSS matrix under -fsanitize=address,undefined (oracle/Makefile's
+    libsangnom_oracle_asan.so): no out-of-bounds tap, no signed overflow, no misaligned access -- and still the numpy
+    restatement's results.  Runs in a child process because the sanitizer runtime has to be preloaded."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    subprocess.check_call(["make", "-s", "-C", odir, "libsangnom_oracle_asan.so"])
+    asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan_rt = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    env = dict(os.environ, SN_ORACLE_LIB=os.path.join(odir, "libsangnom_oracle_asan.so"),
+               LD_PRELOAD=f"{asan_rt}:{ubsan_rt}", ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", _ASAN_CHILD.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
