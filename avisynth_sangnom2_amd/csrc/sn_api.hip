@@ -899,6 +899,132 @@ int sn_debug_read_coupled_rows(sn_context* h, int32_t which, void* host_dst, siz
     return SN_OK;
 }
 
+// ---- the anti-aliasing idiom as one call -------------------------------------------------------
+struct sn_aa_context {
+    sn_config cfg{};
+    sn_context* first = nullptr;   // the turned clip
+    sn_context* second = nullptr;  // the clip itself, on first's stream
+    hipStream_t stream = nullptr;
+    int planes = 1;
+    int w[3] = {0, 0, 0}, h[3] = {0, 0, 0};  // clip geometry per plane
+    int pitch[3] = {0, 0, 0}, tpitch[3] = {0, 0, 0};
+    uint8_t* d_src[3] = {nullptr, nullptr, nullptr};  // clip geometry
+    uint8_t* d_t1[3] = {nullptr, nullptr, nullptr};   // turned: input of the first pass
+    uint8_t* d_u1[3] = {nullptr, nullptr, nullptr};   // turned: its output
+    uint8_t* d_t2[3] = {nullptr, nullptr, nullptr};   // clip geometry: input of the second pass
+    uint8_t* d_out[3] = {nullptr, nullptr, nullptr};
+    std::string err;
+};
+
+static thread_local std::string g_aa_error;
+
+const char* sn_aa_last_error(const sn_aa_context* a) { return a ? a->err.c_str() : g_aa_error.c_str(); }
+
+void sn_aa_destroy(sn_aa_context* a)
+{
+    if (!a) return;
+    (void)hipSetDevice(a->cfg.device);
+    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    if (a->second) sn_destroy(a->second);
+    if (a->first) sn_destroy(a->first);  // owns the stream
+    for (int p = 0; p < 3; ++p)
+        for (uint8_t* q : {a->d_src[p], a->d_t1[p], a->d_u1[p], a->d_t2[p], a->d_out[p]})
+            if (q) (void)hipFree(q);
+    delete a;
+}
+
+int sn_aa_create(const sn_config* cfg, sn_aa_context** out)
+{
+    auto fail_aa = [](sn_aa_context* a, int code, const std::string& msg) {
+        g_aa_error = msg;
+        if (a) sn_aa_destroy(a);
+        return code;
+    };
+    if (!cfg || !out) return fail_aa(nullptr, SN_ERR_INVALID_ARG, "cfg / out is NULL");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(sn_config)) return fail_aa(nullptr, SN_ERR_INVALID_ARG, "sn_config.struct_size mismatch");
+    if (cfg->dh) return fail_aa(nullptr, SN_ERR_UNSUPPORTED, "sn_aa_create: dh is not part of the anti-aliasing idiom");
+    sn_aa_context* a = new (std::nothrow) sn_aa_context();
+    if (!a) return fail_aa(nullptr, SN_ERR_INVALID_ARG, "out of host memory");
+    a->cfg = *cfg;
+    sn_config c1 = *cfg;  // TurnLeft: width <-> height, the chroma subsampling turns with it
+    c1.width = cfg->height;
+    c1.height = cfg->width;
+    c1.sub_w = cfg->sub_h;
+    c1.sub_h = cfg->sub_w;
+    c1.max_batch = 1;
+    c1.mode = SN_MODE_AUTO;
+    c1.stream = nullptr;
+    int rc = sn_create(&c1, &a->first);
+    if (rc != SN_OK) return fail_aa(a, rc, sn_last_error(nullptr));
+    sn_config c2 = *cfg;
+    c2.max_batch = 1;
+    c2.mode = SN_MODE_AUTO;
+    c2.stream = sn_get_stream(a->first);
+    rc = sn_create(&c2, &a->second);
+    if (rc != SN_OK) return fail_aa(a, rc, sn_last_error(nullptr));
+    a->stream = reinterpret_cast<hipStream_t>(sn_get_stream(a->first));
+    a->planes = cfg->num_planes < 3 ? cfg->num_planes : 3;
+    const int B = cfg->bytes_per_sample;
+    for (int p = 0; p < a->planes; ++p) {
+        a->w[p] = p ? cfg->width >> cfg->sub_w : cfg->width;
+        a->h[p] = p ? cfg->height >> cfg->sub_h : cfg->height;
+        a->pitch[p] = (a->w[p] * B + 255) & ~255;
+        a->tpitch[p] = (a->h[p] * B + 255) & ~255;
+        const size_t clip_bytes = (size_t)a->pitch[p] * a->h[p], turned_bytes = (size_t)a->tpitch[p] * a->w[p];
+        for (uint8_t** q : {&a->d_src[p], &a->d_t2[p], &a->d_out[p]})
+            if (hipMalloc(reinterpret_cast<void**>(q), clip_bytes) != hipSuccess) return fail_aa(a, SN_ERR_HIP, "hipMalloc failed (sn_aa_create)");
+        for (uint8_t** q : {&a->d_t1[p], &a->d_u1[p]})
+            if (hipMalloc(reinterpret_cast<void**>(q), turned_bytes) != hipSuccess) return fail_aa(a, SN_ERR_HIP, "hipMalloc failed (sn_aa_create)");
+    }
+    *out = a;
+    return SN_OK;
+}
+
+int sn_aa_process_host(sn_aa_context* a, const void* const src[3], const int32_t sp[3], void* const dst[3], const int32_t dp[3],
+                       int32_t parity)
+{
+    if (!a) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    auto bad = [&](int code, const std::string& m) { a->err = m; return code; };
+    if (!src || !sp || !dst || !dp) return bad(SN_ERR_INVALID_ARG, "plane array is NULL");
+    const int B = a->cfg.bytes_per_sample;
+    for (int p = 0; p < a->planes; ++p)
+        if (!src[p] || !dst[p] || sp[p] < a->w[p] * B || dp[p] < a->w[p] * B) return bad(SN_ERR_INVALID_ARG, "plane pointer is NULL or pitch smaller than the row");
+#define SN_AA_HIP(call)                                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return bad(SN_ERR_HIP, std::string(#call " failed: ") + hipGetErrorString(e_)); \
+    } while (0)
+#define SN_AA_SN(ctx, call)                                                 \
+    do {                                                                    \
+        const int rc_ = (call);                                             \
+        if (rc_ != SN_OK) return bad(rc_, sn_last_error(ctx));              \
+    } while (0)
+    SN_AA_HIP(hipSetDevice(a->cfg.device));
+    for (int p = 0; p < a->planes; ++p)
+        SN_AA_HIP(hipMemcpy2DAsync(a->d_src[p], a->pitch[p], src[p], sp[p], (size_t)a->w[p] * B, a->h[p], hipMemcpyHostToDevice, a->stream));
+    for (int p = 0; p < a->planes; ++p)  // TurnLeft
+        SN_AA_SN(a->first, sn_turn_device(a->first, -1, 1, a->d_src[p], 0, a->pitch[p], a->w[p], a->h[p], a->d_t1[p], 0, a->tpitch[p]));
+    {
+        const void* s3[3] = {a->d_t1[0], a->d_t1[1], a->d_t1[2]};
+        void* d3[3] = {a->d_u1[0], a->d_u1[1], a->d_u1[2]};
+        SN_AA_SN(a->first, sn_process_device(a->first, s3, a->tpitch, d3, a->tpitch, parity));
+    }
+    for (int p = 0; p < a->planes; ++p)  // TurnRight: the turned plane is h wide and w high
+        SN_AA_SN(a->first, sn_turn_device(a->first, +1, 1, a->d_u1[p], 0, a->tpitch[p], a->h[p], a->w[p], a->d_t2[p], 0, a->pitch[p]));
+    {
+        const void* s3[3] = {a->d_t2[0], a->d_t2[1], a->d_t2[2]};
+        void* d3[3] = {a->d_out[0], a->d_out[1], a->d_out[2]};
+        SN_AA_SN(a->second, sn_process_device(a->second, s3, a->pitch, d3, a->pitch, parity));
+    }
+    for (int p = 0; p < a->planes; ++p)
+        SN_AA_HIP(hipMemcpy2DAsync(dst[p], dp[p], a->d_out[p], a->pitch[p], (size_t)a->w[p] * B, a->h[p], hipMemcpyDeviceToHost, a->stream));
+    SN_AA_HIP(hipStreamSynchronize(a->stream));
+#undef SN_AA_HIP
+#undef SN_AA_SN
+    return SN_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop
 

@@ -290,3 +290,51 @@ class SangNomAA:
 
     def synchronize(self):
         self.second.synchronize()
+
+
+class SangNomAAHost:
+    """The same idiom through the C ABI's one-call entry point (sn_aa_create / sn_aa_process_host): host planes in,
+    host planes out, the frame stays on the device between the two passes.  This is what the plugin function
+    SangNomAA (host/sangnom2_avs_plugin.cpp) binds."""
+
+    def __init__(self, clip: ClipFormat, order: int = 1, aa: int = 48, aac: int = 0, luma: bool = True, chroma: bool = True,
+                 device: int = 0, isolated_planes: bool = False, fresh_pool: bool = False):
+        self.clip = clip
+        self._lib = capi.load()
+        cfg = capi.SnConfig(
+            struct_size=ctypes.sizeof(capi.SnConfig), width=clip.width, height=clip.height, bytes_per_sample=clip.bytes,
+            bits_per_sample=clip.bits, num_planes=clip.planes, sub_w=clip.subw, sub_h=clip.subh, order=order, aa=aa, aac=aac,
+            dh=0, luma=int(luma), chroma=int(chroma), device=device, max_batch=1, mode=capi.SN_MODE_AUTO, host_depth=0,
+            isolated_planes=int(isolated_planes), fresh_pool=int(fresh_pool), stream=None)
+        self._h = ctypes.c_void_p()
+        rc = self._lib.sn_aa_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != capi.SN_OK:
+            self._h = None
+            raise SangNomError(rc, self._lib.sn_aa_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sn_aa_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def get_frame(self, src, parity: int = 1):
+        n = min(self.clip.planes, 3)
+        dst = [np.zeros_like(src[p]) for p in range(n)]
+        sp, dp = (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)()
+        spi, dpi = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 3)()
+        for p in range(n):
+            if src[p].dtype != self.clip.dtype or src[p].strides[1] != self.clip.bytes:
+                raise ValueError("planes must be x-contiguous arrays of the clip's sample type")
+            sp[p], dp[p], spi[p], dpi[p] = src[p].ctypes.data, dst[p].ctypes.data, src[p].strides[0], dst[p].strides[0]
+        rc = self._lib.sn_aa_process_host(self._h, sp, spi, dp, dpi, int(parity))
+        if rc != capi.SN_OK:
+            raise SangNomError(rc, self._lib.sn_aa_last_error(self._h).decode())
+        return dst

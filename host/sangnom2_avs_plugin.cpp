@@ -44,7 +44,7 @@ struct AvsHost {
         return e->FunctionExists("propShow") ? e->NewVideoFrameP(v, const_cast<FramePtr*>(&src), 32)
                                              : e->NewVideoFrame(v);  // src/SangNom2.cpp:344
     }
-    static int plane_id(int p) { static const int ids[3] = {PLANAR_Y, PLANAR_U, PLANAR_V}; return ids[p]; }
+    static int plane_id(int p) { static const int ids[4] = {PLANAR_Y, PLANAR_U, PLANAR_V, PLANAR_A}; return ids[p]; }
     static const uint8_t* ReadPtr(const FramePtr& f, int p) { return f->GetReadPtr(plane_id(p)); }
     static uint8_t* WritePtr(const FramePtr& f, int p) { return f->GetWritePtr(plane_id(p)); }
     static int Pitch(const FramePtr& f, int p) { return f->GetPitch(plane_id(p)); }
@@ -66,7 +66,7 @@ public:
     }
 };
 
-AVSValue __cdecl Create_SangNom2(AVSValue args, void*, IScriptEnvironment* env)
+static sangnom::Args reference_args(const AVSValue& args)  // Create_SangNom2's defaults, src/SangNom2.cpp:402-405,429-432
 {
     sangnom::Args a;
     a.order = args[1].AsInt(1);
@@ -77,9 +77,46 @@ AVSValue __cdecl Create_SangNom2(AVSValue args, void*, IScriptEnvironment* env)
     a.luma = args[6].AsBool(true);
     a.chroma = args[7].AsBool(true);
     a.opt = args[8].AsInt(-1);
-    a.isolated = args[9].AsBool(false);  // extensions, see include/sangnom_hip.h: sn_config.isolated_planes,
-    a.fresh = args[10].AsBool(false);    // sn_config.fresh_pool
-    return new SangNom2(args[0].AsClip(), a, env, "SangNom2");
+    return a;
+}
+
+AVSValue __cdecl Create_SangNom2(AVSValue args, void*, IScriptEnvironment* env)
+{
+    return new SangNom2(args[0].AsClip(), reference_args(args), env, "SangNom2");
+}
+
+// SangNom2HIP: SangNom2's arguments plus this implementation's extensions (include/sangnom_hip.h: isolated_planes,
+// fresh_pool; look-ahead depth of GetFrame; HIP device).  A name of its own, so that "SangNom2" keeps the reference's
+// signature byte for byte.
+AVSValue __cdecl Create_SangNom2HIP(AVSValue args, void*, IScriptEnvironment* env)
+{
+    sangnom::Args a = reference_args(args);
+    a.isolated = args[9].AsBool(false);
+    a.fresh = args[10].AsBool(false);
+    a.lookahead = args[11].AsInt(-1);
+    a.device = args[12].AsInt(0);
+    return new SangNom2(args[0].AsClip(), a, env, "SangNom2HIP");
+}
+
+// SangNomAA(clip, order, aa, aac): TurnLeft().SangNom2(order, aa, aac).TurnRight().SangNom2(order, aa, aac) with the frame
+// staying on the device between the passes (sangnom::AAFilter).
+class SangNomAA : public GenericVideoFilter {
+    sangnom::AAFilter<AvsHost> impl_;
+
+public:
+    SangNomAA(PClip child, const sangnom::Args& a, IScriptEnvironment* env) : GenericVideoFilter(child), impl_(child, a, env, "SangNomAA") {}
+    PVideoFrame __stdcall GetFrame(int n, IScriptEnvironment* env) override { return impl_.GetFrame(n, env); }
+    int __stdcall SetCacheHints(int cachehints, int) override { return cachehints == CACHE_GET_MTMODE ? MT_MULTI_INSTANCE : 0; }
+};
+
+AVSValue __cdecl Create_SangNomAA(AVSValue args, void*, IScriptEnvironment* env)
+{
+    sangnom::Args a;
+    a.order = args[1].AsInt(1);
+    a.aa = args[2].AsInt(48);
+    a.aac = args[3].AsInt(0);
+    a.device = args[4].AsInt(0);
+    return new SangNomAA(args[0].AsClip(), a, env);
 }
 
 AVSValue __cdecl Create_SangNom(AVSValue args, void*, IScriptEnvironment* env)
@@ -98,8 +135,11 @@ extern "C" __declspec(dllexport) const char* __stdcall AvisynthPluginInit3(IScri
                                                                            const AVS_Linkage* const vectors)
 {
     AVS_linkage = vectors;
-    env->AddFunction("SangNom2", "c[order]i[aa]i[aac]i[threads]i[dh]b[luma]b[chroma]b[opt]i[isolated]b[fresh]b", Create_SangNom2, 0);
-    env->AddFunction("SangNom", "c[order]i[aa]i[opt]i", Create_SangNom, 0);
+    env->AddFunction("SangNom2", "c[order]i[aa]i[aac]i[threads]i[dh]b[luma]b[chroma]b[opt]i", Create_SangNom2, 0);  // src/SangNom2.cpp:481, byte for byte
+    env->AddFunction("SangNom", "c[order]i[aa]i[opt]i", Create_SangNom, 0);                                        // :482
+    env->AddFunction("SangNom2HIP", "c[order]i[aa]i[aac]i[threads]i[dh]b[luma]b[chroma]b[opt]i[isolated]b[fresh]b[lookahead]i[device]i",
+                     Create_SangNom2HIP, 0);
+    env->AddFunction("SangNomAA", "c[order]i[aa]i[aac]i[device]i", Create_SangNomAA, 0);
     return "SangNom2";
 }
 #endif  // SN_HAVE_AVISYNTH

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <string>
 
@@ -58,7 +59,7 @@ public:
         if (Host::Is420(vi_) && Host::Height(vi_) % 4) env->ThrowError("%s: height must be mod4.", name);
         if (a.order < 0 || a.order > 2) env->ThrowError("%s: order must be between 0..2.", name);
         if (a.aa < 0 || a.aa > 128) env->ThrowError("%s: aa must be between 0..128.", name);
-        if (n == "SangNom2" && (a.aac < 0 || a.aac > 128)) env->ThrowError("%s: aac must be between 0..128.", name);
+        if (n != "SangNom" && (a.aac < 0 || a.aac > 128)) env->ThrowError("%s: aac must be between 0..128.", name);
         if (a.opt < -1 || a.opt > 1) env->ThrowError("%s: opt must be between -1..2.", name);  // sic
 
         sn_config c{};
@@ -91,6 +92,7 @@ public:
         if (rc != SN_OK) env->ThrowError("%s: %s", name, sn_last_error(nullptr));
         if (a.dh) Host::SetHeight(vi_, Host::Height(vi_) * 2);  // src/SangNom2.cpp:284-285
         planes_ = c.num_planes;
+        alpha_ = Host::NumComponents(vi_) == 4;
         num_frames_ = Host::NumFrames(vi_);
         // look-ahead processes frames the caller may never ask for; where results depend on the order of
         // processing (history-carrying configurations) GetFrame therefore stays synchronous
@@ -127,6 +129,7 @@ public:
         const int parity = args_.order == 0 ? (Host::GetParity(child_, n) ? 1 : 0) : 1;
         if (sn_process_host(ctx_, sp, spitch, dp, dpitch, parity) != SN_OK)
             env->ThrowError("SangNom2: %s", sn_last_error(ctx_));
+        CopyAlpha(src, dst);
         return dst;
     }
 
@@ -147,6 +150,20 @@ private:
             if (src) { sp[p] = Host::ReadPtr(src, p); spitch[p] = Host::Pitch(src, p); }
             if (dst) { dp[p] = Host::WritePtr(dst, p); dpitch[p] = Host::Pitch(dst, p); }
         }
+    }
+
+    // EXTENSION: the reference never writes a fourth plane (src/SangNom2.cpp:346-348 stops at
+    // min(NumComponents, 3)), so the alpha of a YUVA clip comes out as whatever the new frame held.  Here it is passed
+    // through: copied line by line, and with dh every source line fills two output lines.
+    void CopyAlpha(const FramePtr& src, const FramePtr& dst) const
+    {
+        if (!alpha_) return;
+        const uint8_t* s = Host::ReadPtr(src, 3);
+        uint8_t* d = Host::WritePtr(dst, 3);
+        const int sp = Host::Pitch(src, 3), dp = Host::Pitch(dst, 3);
+        const size_t row = (size_t)Host::Width(vi_) * Host::ComponentSize(vi_);
+        const int h_out = Host::Height(vi_);
+        for (int y = 0; y < h_out; ++y) std::memcpy(d + (size_t)y * dp, s + (size_t)(args_.dh ? y / 2 : y) * sp, row);
     }
 
     FramePtr Collect(Env* env)
@@ -178,6 +195,7 @@ private:
             Planes(p.src, FramePtr(), sp, spitch, dp, dpitch);
             const int parity = args_.order == 0 ? (Host::GetParity(child_, p.n) ? 1 : 0) : 1;
             if (sn_submit_host(ctx_, sp, spitch, parity, &p.slot) != SN_OK) env->ThrowError("SangNom2: %s", sn_last_error(ctx_));
+            CopyAlpha(p.src, p.dst);
             p.src = FramePtr();
             inflight_.push_back(p);
         }
@@ -194,6 +212,88 @@ private:
     Info vi_{};
     sn_context* ctx_ = nullptr;
     int planes_ = 1;
+    bool alpha_ = false;
+};
+
+// SangNomAA(clip, order, aa, aac): the anti-aliasing idiom TurnLeft().SangNom2(order, aa, aac).TurnRight().SangNom2(order,
+// aa, aac) as one filter over sn_aa_process_host -- the frame crosses PCIe once each way instead of four times
+// (README.md:3 of the reference: "mainly used in anti-aliasing scripts").  Same checks and messages
+// as SangNom2 for the clip itself; the turned clip must pass them as well (e.g. an even WIDTH).
+template <class Host>
+class AAFilter {
+public:
+    using Env = typename Host::Env;
+    using ClipPtr = typename Host::ClipPtr;
+    using FramePtr = typename Host::FramePtr;
+    using Info = typename Host::Info;
+
+    AAFilter(ClipPtr child, const Args& a, Env* env, const char* name = "SangNomAA") : child_(child), args_(a)
+    {
+        vi_ = Host::GetInfo(child);
+        if (Host::IsRGB(vi_) || !Host::IsPlanar(vi_)) env->ThrowError("%s: clip must be in Y/YUV planar format.", name);
+        if (Host::Height(vi_) % 2 != 0) env->ThrowError("%s: height must be even.", name);
+        if (Host::Is420(vi_) && Host::Height(vi_) % 4) env->ThrowError("%s: height must be mod4.", name);
+        if (a.order < 0 || a.order > 2) env->ThrowError("%s: order must be between 0..2.", name);
+        if (a.aa < 0 || a.aa > 128) env->ThrowError("%s: aa must be between 0..128.", name);
+        if (a.aac < 0 || a.aac > 128) env->ThrowError("%s: aac must be between 0..128.", name);
+        sn_config c{};
+        c.struct_size = (int32_t)sizeof c;
+        c.width = Host::Width(vi_);
+        c.height = Host::Height(vi_);
+        c.bytes_per_sample = Host::ComponentSize(vi_);
+        c.bits_per_sample = Host::BitsPerComponent(vi_);
+        c.num_planes = std::min(Host::NumComponents(vi_), 3);
+        c.sub_w = c.num_planes > 1 ? Host::SubW(vi_) : 0;
+        c.sub_h = c.num_planes > 1 ? Host::SubH(vi_) : 0;
+        c.order = a.order;
+        c.aa = a.aa;
+        c.aac = a.aac;
+        c.luma = a.luma;
+        c.chroma = a.chroma;
+        c.device = a.device;
+        c.max_batch = 1;
+        c.isolated_planes = a.isolated ? 1 : 0;
+        c.fresh_pool = a.fresh ? 1 : 0;
+        if (sn_aa_create(&c, &ctx_) != SN_OK) env->ThrowError("%s: %s", name, sn_aa_last_error(nullptr));
+        planes_ = c.num_planes;
+        alpha_ = Host::NumComponents(vi_) == 4;
+    }
+    AAFilter(const AAFilter&) = delete;
+    AAFilter& operator=(const AAFilter&) = delete;
+    ~AAFilter() { sn_aa_destroy(ctx_); }
+
+    const Info& GetInfo() const { return vi_; }
+
+    FramePtr GetFrame(int n, Env* env)
+    {
+        FramePtr src = Host::GetFrame(child_, n, env);
+        FramePtr dst = Host::NewFrame(env, vi_, src);
+        const void* sp[3] = {nullptr, nullptr, nullptr};
+        void* dp[3] = {nullptr, nullptr, nullptr};
+        int32_t spitch[3] = {0, 0, 0}, dpitch[3] = {0, 0, 0};
+        for (int p = 0; p < planes_; ++p) {
+            sp[p] = Host::ReadPtr(src, p);
+            dp[p] = Host::WritePtr(dst, p);
+            spitch[p] = Host::Pitch(src, p);
+            dpitch[p] = Host::Pitch(dst, p);
+        }
+        const int parity = args_.order == 0 ? (Host::GetParity(child_, n) ? 1 : 0) : 1;
+        if (sn_aa_process_host(ctx_, sp, spitch, dp, dpitch, parity) != SN_OK) env->ThrowError("SangNomAA: %s", sn_aa_last_error(ctx_));
+        if (alpha_) {  // passed through (see Filter::CopyAlpha)
+            const size_t row = (size_t)Host::Width(vi_) * Host::ComponentSize(vi_);
+            for (int y = 0; y < Host::Height(vi_); ++y)
+                std::memcpy(Host::WritePtr(dst, 3) + (size_t)y * Host::Pitch(dst, 3), Host::ReadPtr(src, 3) + (size_t)y * Host::Pitch(src, 3), row);
+        }
+        return dst;
+    }
+
+private:
+    ClipPtr child_;
+    Args args_;
+    Info vi_{};
+    sn_aa_context* ctx_ = nullptr;
+    int planes_ = 1;
+    bool alpha_ = false;
 };
 
 // Legacy SangNom(clip, order, aa, opt): order 0/1/2 = bottom/top/double-rate is remapped to

@@ -26,20 +26,20 @@ struct ClipInfo {  // the VideoInfo fields the filter reads (SangNom2.cpp:281-28
     int width = 0, height = 0;
     int component_size = 1;    // bytes per sample
     int bits_per_component = 8;
-    int num_components = 1;    // 1 = Y, 3 = YUV
+    int num_components = 1;    // 1 = Y, 3 = YUV, 4 = YUVA (alpha: luma-sized)
     int sub_w = 0, sub_h = 0;  // log2 chroma subsampling
     int num_frames = 0;
     bool rgb = false, planar = true;
     bool Is420() const { return num_components >= 3 && sub_w == 1 && sub_h == 1; }
-    int PlaneWidth(int p) const { return p == 0 ? width : width >> sub_w; }
-    int PlaneHeight(int p) const { return p == 0 ? height : height >> sub_h; }
+    int PlaneWidth(int p) const { return (p == 0 || p == 3) ? width : width >> sub_w; }
+    int PlaneHeight(int p) const { return (p == 0 || p == 3) ? height : height >> sub_h; }
 };
 
 class Frame {  // a pitched planar frame
 public:
     Frame(const ClipInfo& vi, int align = 32) : vi_(vi)
     {
-        for (int p = 0; p < vi.num_components && p < 3; ++p) {
+        for (int p = 0; p < vi.num_components && p < 4; ++p) {
             const int row = vi.PlaneWidth(p) * vi.component_size;
             pitch_[p] = (row + align - 1) / align * align + align;  // deliberately wider than the row
             data_[p].assign((size_t)pitch_[p] * vi.PlaneHeight(p), 0xEE);
@@ -54,8 +54,8 @@ public:
 
 private:
     ClipInfo vi_;
-    std::vector<uint8_t> data_[3];
-    int pitch_[3] = {0, 0, 0};
+    std::vector<uint8_t> data_[4];
+    int pitch_[4] = {0, 0, 0, 0};
 };
 using FramePtr = std::shared_ptr<Frame>;
 

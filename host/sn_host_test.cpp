@@ -2,9 +2,10 @@
 // engine drives the reference plugin: build a source clip, construct SangNom2(clip, ...), request
 // frames with GetFrame(n).  tests/test_host_adapter.py feeds it frames and compares the output with
 // the oracle.
-//   sn_host_test <in.bin> <out.bin> [lookahead [first-frame-order...]]
-// lookahead > 1 runs GetFrame over the host ring; the optional list gives the order in which frames are
-// requested (default 0 .. nframes-1), e.g. to exercise a seek.
+//   sn_host_test <in.bin> <out.bin> [lookahead | aa [first-frame-order...]]
+// lookahead > 1 runs GetFrame over the host ring; "aa" constructs SangNomAA (sangnom::AAFilter) instead of SangNom2;
+// the optional list gives the order in which frames are requested (default 0 .. nframes-1), e.g. to exercise a seek.
+// planes = 4 in the header is a YUVA clip: the fourth plane is luma-sized and passed through.
 // in.bin : 14 x int32 {w,h,bytes,bits,planes,subw,subh,order,aa,aac,dh,luma,chroma,nframes}, then per
 //          frame: int32 parity + the planes, tightly packed.
 // out.bin: per frame the output planes, tightly packed.  On a constructor error: exit code 3 and
@@ -62,7 +63,8 @@ int main(int argc, char** argv)
     a.chroma = h[12] != 0;
     const int nframes = h[13];
     clip->vi.num_frames = nframes;
-    if (argc > 3) a.lookahead = atoi(argv[3]);
+    const bool aa_idiom = argc > 3 && strcmp(argv[3], "aa") == 0;
+    if (argc > 3 && !aa_idiom) a.lookahead = atoi(argv[3]);
     std::vector<int> order;
     for (int i = 4; i < argc; ++i) order.push_back(atoi(argv[i]));
     if (order.empty())
@@ -82,14 +84,19 @@ int main(int argc, char** argv)
 
     Env env;
     try {
-        sangnom::Filter<TestHost> flt(clip, a, &env);
         FILE* out = fopen(argv[2], "wb");
         if (!out) return 2;
-        for (int n : order) {
-            FramePtr d = flt.GetFrame(n, &env);
+        auto dump = [&](const FramePtr& d) {
             for (int p = 0; p < clip->vi.num_components; ++p)
                 for (int y = 0; y < d->Height(p); ++y)
                     fwrite(d->Ptr(p) + (size_t)y * d->Pitch(p), 1, d->RowSize(p), out);
+        };
+        if (aa_idiom) {
+            sangnom::AAFilter<TestHost> flt(clip, a, &env);
+            for (int n : order) dump(flt.GetFrame(n, &env));
+        } else {
+            sangnom::Filter<TestHost> flt(clip, a, &env);
+            for (int n : order) dump(flt.GetFrame(n, &env));
         }
         fclose(out);
     } catch (const Error& e) {

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 1
+#define SN_ABI_VERSION 2
 
 typedef struct sn_context sn_context;
 
@@ -162,6 +162,22 @@ int sn_collect_host(sn_context* ctx, int32_t slot, void* const dst[3], const int
 int sn_turn_device(sn_context* ctx, int32_t direction, int32_t nframes, const void* src, int64_t src_frame_stride,
                    int32_t src_pitch, int32_t width, int32_t height, void* dst, int64_t dst_frame_stride,
                    int32_t dst_pitch);
+
+/* The anti-aliasing idiom TurnLeft().SangNom2(order, aa, aac).TurnRight().SangNom2(order, aa, aac) as ONE call with
+ * host planes (README.md:3 of the reference: "mainly used in anti-aliasing scripts"): the frame
+ * crosses PCIe once each way and stays on the device between the two passes (two filter instances -- one for the
+ * turned clip, one for the clip itself -- on one stream, sn_turn_device in between).  `cfg` describes the clip
+ * (dh must be 0; luma / chroma / isolated_planes / fresh_pool / device apply to both passes; max_batch, mode, stream and
+ * host_depth are ignored); the turned clip must pass the reference's checks too (sn_aa_create reports the first
+ * pass's message otherwise).  The result is what that script gives with the reference: two instances, so for widths
+ * or heights that are not a multiple of 32 each pass carries its own pool history from frame to frame.  Not a
+ * function of the reference; host/sangnom2_avs_plugin.cpp registers it as SangNomAA. */
+typedef struct sn_aa_context sn_aa_context;
+int sn_aa_create(const sn_config* cfg, sn_aa_context** out);
+int sn_aa_process_host(sn_aa_context* ctx, const void* const src[3], const int32_t src_pitch[3], void* const dst[3],
+                       const int32_t dst_pitch[3], int32_t parity);
+const char* sn_aa_last_error(const sn_aa_context* ctx); /* ctx == NULL: last failed sn_aa_create on this thread */
+void sn_aa_destroy(sn_aa_context* ctx);
 
 int sn_synchronize(sn_context* ctx);
 void* sn_get_stream(sn_context* ctx); /* the hipStream_t the context launches on */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(hip_lib, name), f"libsangnom_hip.so does not export {name}"
-    assert hip_lib.sn_abi_version() == 1
+    assert hip_lib.sn_abi_version() == 2  # 2: + sn_aa_* (round 2)
 
 
 def test_validate_matches_reference_messages(hip_lib):

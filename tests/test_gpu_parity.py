@@ -10,7 +10,7 @@ from contextlib import nullcontext as _nullcontext
 import numpy as np
 import pytest
 
-from avisynth_sangnom2_amd import ClipFormat, SangNom, SangNom2, SangNomAA, SangNomError, clip_format, synth
+from avisynth_sangnom2_amd import ClipFormat, SangNom, SangNom2, SangNomAA, SangNomAAHost, SangNomError, clip_format, synth
 from oracle.oracle import Oracle
 from oracle.sangnom_numpy import NumpySangNom
 from tests.util import describe_diff, make_frames, oracle_cfg, same
@@ -850,3 +850,21 @@ def test_non_finite_float_samples_follow_the_reference_ladder(hip_lib, mode):
     ok = (a.view(np.uint32) == got.view(np.uint32)) | (np.isnan(a) & np.isnan(got))
     bad = np.argwhere(written & ~ok)
     assert len(bad) == 0, f"{len(bad)} defined samples differ, first {bad[:4].tolist()}: {a[written & ~ok][:4]} vs {got[written & ~ok][:4]}"
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", AA_CASES[:6], ids=[f"{c[0]}-{c[1]}x{c[2]}-{i}" for i, c in enumerate(AA_CASES[:6])])
+def test_anti_aliasing_entry_point_of_the_c_abi(hip_lib, fmt, w, h, kw):
+    """sn_aa_process_host (what the plugin function SangNomAA binds): host frames through
+    TurnLeft -> SangNom2 -> TurnRight -> SangNom2 in one call == the script with two oracle instances and numpy turns."""
+    clip = clip_format(fmt, w, h)
+    turned = ClipFormat(width=h, height=w, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subh, subh=clip.subw)
+    first, second = Oracle(oracle_cfg(turned, **kw)), Oracle(oracle_cfg(clip, **kw))
+    with SangNomAAHost(clip, **kw) as aa:
+        for f, fr in enumerate(make_frames(clip, "noise", 3, seed0=17)):
+            a = first.process([np.ascontiguousarray(np.rot90(pl, k=1)) for pl in fr])
+            want = second.process([np.ascontiguousarray(np.rot90(pl, k=-1)) for pl in a])
+            got = aa.get_frame(fr)
+            for p in range(clip.planes):
+                assert same(want[p], got[p]), f"frame {f} plane {p}: " + describe_diff(want[p], got[p])
+    with pytest.raises(SangNomError, match="height must be even"):  # the TURNED clip fails the reference's check
+        SangNomAAHost(clip_format("Y8", 63, 64))

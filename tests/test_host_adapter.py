@@ -104,3 +104,63 @@ def test_getframe_with_lookahead_and_a_seek(tmp_path, fmt, w, h, kw):
             pos += wpl.nbytes
             assert same(wpl, got), f"{fmt} request {n} plane {p}"
     assert pos == raw.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 128, 64, dict(aa=48)), ("YUV420P8", 128, 64, dict(aa=48, aac=48)),
+                                        ("Y16", 96, 80, dict(aa=30, order=2))])
+def test_plugin_level_anti_aliasing_function(tmp_path, fmt, w, h, kw):
+    """SangNomAA(clip, order, aa, aac) of the plugin (sangnom::AAFilter over sn_aa_process_host) == the script
+    TurnLeft().SangNom2(...).TurnRight().SangNom2(...) run with two oracle instances and numpy turns."""
+    from avisynth_sangnom2_amd import ClipFormat
+    clip = clip_format(fmt, w, h)
+    turned = ClipFormat(width=h, height=w, bytes=clip.bytes, bits=clip.bits, planes=clip.planes, subw=clip.subh, subh=clip.subw)
+    frames = [synth.frame(clip, "noise", seed=11 + i) for i in range(3)]
+    r, fout = _run(tmp_path, clip, kw, frames, [1, 1, 1], extra=["aa"])
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    first, second = Oracle(oracle_cfg(turned, **kw)), Oracle(oracle_cfg(clip, **kw))
+    raw = np.fromfile(fout, dtype=np.uint8)
+    pos = 0
+    for f, fr in enumerate(frames):
+        a = first.process([np.ascontiguousarray(np.rot90(pl, k=1)) for pl in fr])
+        want = second.process([np.ascontiguousarray(np.rot90(pl, k=-1)) for pl in a])
+        for p, wpl in enumerate(want):
+            got = raw[pos:pos + wpl.nbytes].view(wpl.dtype).reshape(wpl.shape)
+            pos += wpl.nbytes
+            assert same(wpl, got), f"{fmt} frame {f} plane {p}"
+    assert pos == raw.size
+
+
+def test_anti_aliasing_function_checks_the_turned_clip_too(tmp_path):
+    r, _ = _run(tmp_path, clip_format("Y8", 63, 64), {}, [], [], extra=["aa"])
+    assert r.returncode == 3 and "height must be even" in r.stdout, (r.returncode, r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dh,lookahead", [(False, 1), (True, 1), (False, 4)])
+def test_alpha_plane_is_passed_through(tmp_path, dh, lookahead):
+    """A YUVA clip: the reference leaves the fourth plane of the new frame unwritten (src/SangNom2.cpp:346-348); the
+    adapter copies it (dh: every source line twice).  Y, U, V are the oracle's."""
+    w, h = 128, 64
+    clip = clip_format("YUV420P8", w, h)
+    kw = dict(aac=48, dh=dh)
+    rng = np.random.default_rng(12)
+    frames, alphas = [], []
+    for i in range(5):
+        fr = synth.frame(clip, "noise", seed=60 + i)
+        alphas.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+        frames.append(list(fr) + [alphas[-1]])
+    yuva = clip_format("YUV420P8", w, h)
+    yuva.planes = 4
+    r, fout = _run(tmp_path, yuva, kw, frames, [1] * 5, extra=[lookahead])
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    raw = np.fromfile(fout, dtype=np.uint8)
+    pos = 0
+    for f in range(5):
+        want = Oracle(oracle_cfg(clip, **kw)).process(frames[f][:3])
+        want.append(np.repeat(alphas[f], 2, axis=0) if dh else alphas[f])
+        for p, wpl in enumerate(want):
+            got = raw[pos:pos + wpl.nbytes].view(wpl.dtype).reshape(wpl.shape)
+            pos += wpl.nbytes
+            assert same(wpl, got), f"frame {f} plane {p}"
+    assert pos == raw.size
