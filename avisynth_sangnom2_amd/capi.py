@@ -24,6 +24,7 @@ EXPORTS = (
     "sn_get_stream", "sn_get_info", "sn_debug_read_pool", "sn_debug_read_coupled_rows",
     "sn_host_slots", "sn_submit_host", "sn_collect_host", "sn_turn_device",
     "sn_aa_create", "sn_aa_process_host", "sn_aa_last_error", "sn_aa_destroy",
+    "sn_pin_host_buffer", "sn_unpin_host_buffer", "sn_submit_host_to",
 )
 
 
@@ -103,6 +104,9 @@ def load():
     L.sn_get_info.argtypes = [vp, ctypes.POINTER(SnInfo)]
     L.sn_debug_read_pool.argtypes = [vp, i32, vp, ctypes.c_size_t]
     L.sn_debug_read_coupled_rows.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    L.sn_pin_host_buffer.argtypes = [vp, ctypes.c_size_t]
+    L.sn_unpin_host_buffer.argtypes = [vp]
+    L.sn_submit_host_to.argtypes = [vp, p3v, p3i, p3v, p3i, i32, ctypes.POINTER(i32)]
     L.sn_aa_create.argtypes = [ctypes.POINTER(SnConfig), ctypes.POINTER(vp)]
     L.sn_aa_process_host.argtypes = [vp, p3v, p3i, p3v, p3i, i32]
     L.sn_aa_last_error.argtypes = [vp]

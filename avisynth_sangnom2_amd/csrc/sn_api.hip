@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -64,6 +65,13 @@ struct Context {
     std::vector<HostGroup> ring;
     std::vector<uint8_t> slot_state;
     std::vector<int32_t> slot_parity;
+    struct SlotDst {  // sn_submit_host_to: where the slot's output goes (pinned planes: straight from the device)
+        void* ptr[3] = {nullptr, nullptr, nullptr};
+        int32_t pitch[3] = {0, 0, 0};
+        bool direct[3] = {false, false, false};
+        bool given = false;
+    };
+    std::vector<SlotDst> slot_dst;
     uint8_t* ring_pin_in[3] = {nullptr, nullptr, nullptr};   // [slot][plane bytes], one allocation per plane
     uint8_t* ring_pin_out[3] = {nullptr, nullptr, nullptr};
     uint8_t* ring_dev_in[3] = {nullptr, nullptr, nullptr};
@@ -100,6 +108,24 @@ struct Context {
 };
 
 static thread_local std::string g_last_error;
+
+// Host memory the caller has pinned through sn_pin_host_buffer (process-wide; a handful of ranges)
+struct PinnedRange {
+    uintptr_t lo, hi;
+};
+static std::mutex g_pin_mutex;
+static std::vector<PinnedRange> g_pinned;
+
+// is the plane [p, p + pitch * (rows - 1) + row_bytes) inside pinned memory?
+static bool plane_is_pinned(const void* p, int pitch, int row_bytes, int rows)
+{
+    if (rows <= 0) return false;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + (uintptr_t)pitch * (rows - 1) + row_bytes;
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    for (const PinnedRange& r : g_pinned)
+        if (lo >= r.lo && hi <= r.hi) return true;
+    return false;
+}
 
 static int fail(Context* c, int code, const char* fmt, ...)
 {
@@ -646,6 +672,8 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
             SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_dst[p]),
                                 (size_t)c->stage_dst_pitch[p] * c->plane_h_out(p)));
         }
+        // (a plane inside memory the caller pinned is DMA'd as it lies; a pageable one goes through the runtime's own
+        // staging -- either way one call)
         SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p], c->stage_src_pitch[p], src[p], sp[p],
                                    (size_t)c->plane_w(p) * B, c->plane_h_in(p), hipMemcpyHostToDevice, c->stream));
     }
@@ -692,6 +720,7 @@ static int ensure_ring(Context* c)
     }
     c->slot_state.assign(depth, Context::kFree);
     c->slot_parity.assign(depth, 1);
+    c->slot_dst.assign(depth, Context::SlotDst{});
     c->ring.resize(groups);
     for (auto& g : c->ring) {
         SN_HIP(c, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
@@ -727,9 +756,29 @@ static int launch_ring_group(Context* c, int gi)
                              c->ring_pitch_out, &c->slot_parity[first]);
     if (rc != SN_OK) return rc;
     SN_HIP(c, hipEventRecord(g.swept, g.stream));
-    for (int p = 0; p < c->nplanes(); ++p)
-        SN_HIP(c, hipMemcpyAsync(c->ring_pin_out[p] + (int64_t)first * c->ring_bytes_out[p], ddst[p], (size_t)c->ring_bytes_out[p] * n,
-                                 hipMemcpyDeviceToHost, g.stream));
+    const int B = c->cfg.bytes_per_sample;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        bool any_direct = false;
+        for (int k = 0; k < n; ++k) any_direct = any_direct || c->slot_dst[first + k].direct[p];
+        if (!any_direct) {  // the whole group's plane p in one transfer into the pinned staging
+            SN_HIP(c, hipMemcpyAsync(c->ring_pin_out[p] + (int64_t)first * c->ring_bytes_out[p], ddst[p], (size_t)c->ring_bytes_out[p] * n,
+                                     hipMemcpyDeviceToHost, g.stream));
+            continue;
+        }
+        for (int k = 0; k < n; ++k) {
+            const Context::SlotDst& sd = c->slot_dst[first + k];
+            const uint8_t* from = static_cast<const uint8_t*>(ddst[p]) + (int64_t)k * c->ring_bytes_out[p];
+            if (sd.direct[p] && sd.pitch[p] == c->ring_pitch_out[p])  // the caller's pinned plane, same pitch: one linear transfer
+                SN_HIP(c, hipMemcpyAsync(sd.ptr[p], from, (size_t)c->ring_bytes_out[p] - (c->ring_pitch_out[p] - c->plane_w(p) * B),
+                                         hipMemcpyDeviceToHost, g.stream));
+            else if (sd.direct[p])  // ... straight from the device, row by row
+                SN_HIP(c, hipMemcpy2DAsync(sd.ptr[p], sd.pitch[p], from, c->ring_pitch_out[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p),
+                                           hipMemcpyDeviceToHost, g.stream));
+            else
+                SN_HIP(c, hipMemcpyAsync(c->ring_pin_out[p] + (int64_t)(first + k) * c->ring_bytes_out[p], from, (size_t)c->ring_bytes_out[p],
+                                         hipMemcpyDeviceToHost, g.stream));
+        }
+    }
     SN_HIP(c, hipEventRecord(g.done, g.stream));
     for (int k = 0; k < n; ++k) c->slot_state[first + k] = Context::kInFlight;
     g.lo = g.hi;
@@ -745,7 +794,8 @@ int sn_host_slots(sn_context* h)
     return (int)c->slot_state.size();
 }
 
-int sn_submit_host(sn_context* h, const void* const src[3], const int32_t sp[3], int32_t parity, int32_t* slot_out)
+static int submit_impl(sn_context* h, const void* const src[3], const int32_t sp[3], void* const dst[3], const int32_t dp[3], int32_t parity,
+                       int32_t* slot_out)
 {
     Context* c = reinterpret_cast<Context*>(h);
     if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
@@ -765,14 +815,39 @@ int sn_submit_host(sn_context* h, const void* const src[3], const int32_t sp[3],
     Context::HostGroup& g = c->ring[gi];
     if (k == 0) g.lo = g.hi = 0;  // the ring came round to this group again
 
+    Context::SlotDst sd{};
+    if (dst) {
+        if (!dp) return sn::fail(c, SN_ERR_INVALID_ARG, "plane array is NULL");
+        sd.given = true;
+        for (int p = 0; p < c->nplanes(); ++p) {
+            if (!dst[p]) return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pointer is NULL", p);
+            if (dp[p] < c->plane_w(p) * B) return sn::fail(c, SN_ERR_INVALID_ARG, "plane %d pitch smaller than the row size %d", p, c->plane_w(p) * B);
+            sd.ptr[p] = dst[p];
+            sd.pitch[p] = dp[p];
+            sd.direct[p] = sn::plane_is_pinned(dst[p], dp[p], c->plane_w(p) * B, c->plane_h_out(p));
+        }
+    }
+    c->slot_dst[slot] = sd;
+    // source planes: pinned ones are DMA'd as they lie, the others are staged (copy threads) first
     Copier::Job jobs[3];
-    for (int p = 0; p < c->nplanes(); ++p)
-        jobs[p] = {c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p], static_cast<const uint8_t*>(src[p]), c->ring_pitch_in[p], sp[p],
-                   c->plane_w(p) * B, c->plane_h_in(p)};
-    c->copier->run(jobs, c->nplanes());
-    for (int p = 0; p < c->nplanes(); ++p)
-        SN_HIP(c, hipMemcpyAsync(c->ring_dev_in[p] + (int64_t)slot * c->ring_bytes_in[p], c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p],
-                                 (size_t)c->ring_bytes_in[p], hipMemcpyHostToDevice, g.stream));
+    bool direct_in[3] = {false, false, false};
+    int njobs = 0;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        direct_in[p] = sn::plane_is_pinned(src[p], sp[p], c->plane_w(p) * B, c->plane_h_in(p));
+        if (!direct_in[p])
+            jobs[njobs++] = {c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p], static_cast<const uint8_t*>(src[p]), c->ring_pitch_in[p], sp[p],
+                             c->plane_w(p) * B, c->plane_h_in(p)};
+    }
+    if (njobs) c->copier->run(jobs, njobs);
+    for (int p = 0; p < c->nplanes(); ++p) {
+        uint8_t* dev = c->ring_dev_in[p] + (int64_t)slot * c->ring_bytes_in[p];
+        if (direct_in[p] && sp[p] == c->ring_pitch_in[p])  // same pitch on both sides: one linear transfer
+            SN_HIP(c, hipMemcpyAsync(dev, src[p], (size_t)c->ring_bytes_in[p] - (c->ring_pitch_in[p] - c->plane_w(p) * B), hipMemcpyHostToDevice, g.stream));
+        else if (direct_in[p])
+            SN_HIP(c, hipMemcpy2DAsync(dev, c->ring_pitch_in[p], src[p], sp[p], (size_t)c->plane_w(p) * B, c->plane_h_in(p), hipMemcpyHostToDevice, g.stream));
+        else
+            SN_HIP(c, hipMemcpyAsync(dev, c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p], (size_t)c->ring_bytes_in[p], hipMemcpyHostToDevice, g.stream));
+    }
     c->slot_state[slot] = Context::kStaged;
     c->slot_parity[slot] = parity;
     g.hi = k + 1;
@@ -782,12 +857,28 @@ int sn_submit_host(sn_context* h, const void* const src[3], const int32_t sp[3],
     return SN_OK;
 }
 
-int sn_collect_host(sn_context* h, int32_t slot, void* const dst[3], const int32_t dp[3])
+int sn_submit_host(sn_context* h, const void* const src[3], const int32_t sp[3], int32_t parity, int32_t* slot_out)
+{
+    return submit_impl(h, src, sp, nullptr, nullptr, parity, slot_out);
+}
+
+int sn_submit_host_to(sn_context* h, const void* const src[3], const int32_t sp[3], void* const dst[3], const int32_t dp[3], int32_t parity,
+                      int32_t* slot_out)
+{
+    if (!dst || !dp) return sn::fail(reinterpret_cast<Context*>(h), SN_ERR_INVALID_ARG, "plane array is NULL");
+    return submit_impl(h, src, sp, dst, dp, parity, slot_out);
+}
+
+int sn_collect_host(sn_context* h, int32_t slot, void* const dst_arg[3], const int32_t dp_arg[3])
 {
     Context* c = reinterpret_cast<Context*>(h);
     if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
     if (slot < 0 || slot >= (int)c->slot_state.size() || c->slot_state[slot] == Context::kFree)
         return sn::fail(c, SN_ERR_INVALID_ARG, "slot %d holds no frame", slot);
+    // the destination: named now, or at submission (sn_submit_host_to)
+    const Context::SlotDst sd = c->slot_dst[slot];
+    void* const* dst = dst_arg ? dst_arg : (sd.given ? sd.ptr : nullptr);
+    const int32_t* dp = dst_arg ? dp_arg : (sd.given ? sd.pitch : nullptr);
     if (!dst || !dp) return sn::fail(c, SN_ERR_INVALID_ARG, "plane array is NULL");
     const int B = c->cfg.bytes_per_sample;
     for (int p = 0; p < c->nplanes(); ++p) {
@@ -802,11 +893,47 @@ int sn_collect_host(sn_context* h, int32_t slot, void* const dst[3], const int32
     }
     SN_HIP(c, hipEventSynchronize(c->ring[gi].done));
     Copier::Job jobs[3];
-    for (int p = 0; p < c->nplanes(); ++p)
-        jobs[p] = {static_cast<uint8_t*>(dst[p]), c->ring_pin_out[p] + (int64_t)slot * c->ring_bytes_out[p], dp[p], c->ring_pitch_out[p],
-                   c->plane_w(p) * B, c->plane_h_out(p)};
-    c->copier->run(jobs, c->nplanes());
+    int njobs = 0;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        if (sd.direct[p] && dst[p] == sd.ptr[p]) continue;  // already written there by the device
+        const uint8_t* from = c->ring_pin_out[p] + (int64_t)slot * c->ring_bytes_out[p];
+        if (sd.direct[p]) {  // collected into another place than announced: that plane never reached the staging
+            SN_HIP(c, hipMemcpy2D(dst[p], dp[p], sd.ptr[p], sd.pitch[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyHostToHost));
+            continue;
+        }
+        jobs[njobs++] = {static_cast<uint8_t*>(dst[p]), from, dp[p], c->ring_pitch_out[p], c->plane_w(p) * B, c->plane_h_out(p)};
+    }
+    if (njobs) c->copier->run(jobs, njobs);
     c->slot_state[slot] = Context::kFree;
+    c->slot_dst[slot] = Context::SlotDst{};
+    return SN_OK;
+}
+
+int sn_pin_host_buffer(void* ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "sn_pin_host_buffer: NULL or empty");
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) return sn::fail(nullptr, SN_ERR_HIP, "hipHostRegister failed: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(sn::g_pin_mutex);
+    sn::g_pinned.push_back({reinterpret_cast<uintptr_t>(ptr), reinterpret_cast<uintptr_t>(ptr) + bytes});
+    return SN_OK;
+}
+
+int sn_unpin_host_buffer(void* ptr)
+{
+    {
+        std::lock_guard<std::mutex> lk(sn::g_pin_mutex);
+        bool found = false;
+        for (size_t i = 0; i < sn::g_pinned.size(); ++i)
+            if (sn::g_pinned[i].lo == reinterpret_cast<uintptr_t>(ptr)) {
+                sn::g_pinned.erase(sn::g_pinned.begin() + (long)i);
+                found = true;
+                break;
+            }
+        if (!found) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "sn_unpin_host_buffer: not pinned through sn_pin_host_buffer");
+    }
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) return sn::fail(nullptr, SN_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
     return SN_OK;
 }
 

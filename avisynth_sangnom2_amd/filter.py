@@ -177,15 +177,23 @@ class SangNom2:
             ptr[p], pitch[p] = a.ctypes.data, a.strides[0]
         return ptr, pitch
 
-    def submit(self, src, parity: int = 1) -> int:
-        """Queue one host frame (H2D, sweeps, D2H on a ring slot's own stream); returns the slot."""
+    def submit(self, src, parity: int = 1, dst=None) -> int:
+        """Queue one host frame (H2D, sweeps, D2H on a ring slot's own stream); returns the slot.  With `dst` the
+        output planes are named now (sn_submit_host_to): pinned ones are written straight from the device."""
         sp, spi = self._plane_args(src, self.plane_shape_in)
         slot = ctypes.c_int32(-1)
-        self._check(self._lib.sn_submit_host(self._h, sp, spi, int(parity), ctypes.byref(slot)))
+        if dst is None:
+            self._check(self._lib.sn_submit_host(self._h, sp, spi, int(parity), ctypes.byref(slot)))
+        else:
+            dp, dpi = self._plane_args(dst, self.plane_shape_out)
+            self._check(self._lib.sn_submit_host_to(self._h, sp, spi, dp, dpi, int(parity), ctypes.byref(slot)))
         return slot.value
 
-    def collect(self, slot: int, dst=None):
-        """Wait for the frame in `slot` and copy it into host planes."""
+    def collect(self, slot: int, dst=None, announced: bool = False):
+        """Wait for the frame in `slot` and copy it into host planes (announced: they were named at submission)."""
+        if announced:
+            self._check(self._lib.sn_collect_host(self._h, int(slot), None, None))
+            return dst
         if dst is None:
             dst = [np.zeros(self.plane_shape_out(p), dtype=self.clip.dtype) for p in range(self.nplanes)]
         dp, dpi = self._plane_args(dst, self.plane_shape_out)
@@ -233,6 +241,20 @@ class SangNom2:
             par = (ctypes.c_int32 * N)(*[int(x) for x in parity])
         self._check(self._lib.sn_process_device_strided(self._h, N, sp, sfs, spi, dp, dfs, dpi, par))
         return dst
+
+
+def pin_host_array(a: np.ndarray) -> None:
+    """sn_pin_host_buffer on a numpy array's memory: frames inside it then move over PCIe without staging copies.
+    Keep the array alive and call unpin_host_array before dropping it."""
+    rc = capi.load().sn_pin_host_buffer(a.ctypes.data, a.nbytes)
+    if rc != capi.SN_OK:
+        raise SangNomError(rc, capi.load().sn_last_error(None).decode())
+
+
+def unpin_host_array(a: np.ndarray) -> None:
+    rc = capi.load().sn_unpin_host_buffer(a.ctypes.data)
+    if rc != capi.SN_OK:
+        raise SangNomError(rc, capi.load().sn_last_error(None).decode())
 
 
 def SangNom(clip: ClipFormat, order: int = 1, aa: int = 48, opt: int = -1, **kw) -> SangNom2:

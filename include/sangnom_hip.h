@@ -155,6 +155,18 @@ int sn_submit_host(sn_context* ctx, const void* const src[3], const int32_t src_
                    int32_t* slot);
 int sn_collect_host(sn_context* ctx, int32_t slot, void* const dst[3], const int32_t dst_pitch[3]);
 
+/* Pinned host frames (optional).  A host that owns its frame memory can pin it once (hipHostRegister under the
+ * hood; the caller keeps the memory alive and unpins it before freeing it).  Planes that lie inside pinned memory move
+ * over PCIe directly: sn_process_host and sn_submit_host skip the staging copy of the source, and sn_submit_host_to
+ * -- sn_submit_host with the destination planes named at submission, as a plugin's GetFrame has them
+ * (env->NewVideoFrame before the kernel runs, src/SangNom2.cpp:344) -- has the output written straight into them;
+ * sn_collect_host (dst = NULL allowed then) only waits.  Unpinned planes take the staged route as before, plane by
+ * plane.  Process-wide registry, thread-safe. */
+int sn_pin_host_buffer(void* ptr, size_t bytes);
+int sn_unpin_host_buffer(void* ptr);
+int sn_submit_host_to(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3], void* const dst[3],
+                      const int32_t dst_pitch[3], int32_t parity, int32_t* slot);
+
 /* TurnRight (direction > 0, clockwise) / TurnLeft (direction < 0) of `nframes` device-resident planes of
  * width x height samples of the context's sample type, on the context's stream: dst is height wide and width
  * high.  For pipelines that keep frames on the GPU between the two SangNom2 passes of an anti-aliasing script

@@ -52,6 +52,40 @@ def main():
             while inflight:
                 flt.collect(inflight.pop(0), dst)
             out[f"ring{slots}_fps"] = round(a.frames / (time.perf_counter() - t0), 1)
+
+    # the same with the host's frames in pinned memory (sn_pin_host_buffer) and the destination named at submission
+    from avisynth_sangnom2_amd import pin_host_array, unpin_host_array
+    for depth in [int(x) for x in a.depths.split(",")][-3:]:
+        with SangNom2(clip, host_depth=depth, **kw) as flt:
+            slots = flt.host_slots()
+            n = flt.nplanes
+            src_arena = [np.stack([ring[i][p] for i in range(8)]) for p in range(n)]
+            dst_arena = [np.zeros((slots,) + flt.plane_shape_out(p), dtype=clip.dtype) for p in range(n)]
+            for x in src_arena + dst_arena:
+                pin_host_array(x)
+            try:
+                with SangNom2(clip, **kw) as sync:
+                    m = max(8, a.frames // 8)
+                    sync.get_frame([src_arena[p][0] for p in range(n)], dst=[dst_arena[p][0] for p in range(n)])
+                    t0 = time.perf_counter()
+                    for f in range(m):
+                        sync.get_frame([src_arena[p][f % 8] for p in range(n)], dst=[dst_arena[p][0] for p in range(n)])
+                    out["sync_pinned_fps"] = round(m / (time.perf_counter() - t0), 1)
+                inflight = []
+                t0 = None
+                for f in range(a.frames + slots):
+                    if f == slots:
+                        t0 = time.perf_counter()  # the first round is the warm-up
+                    if len(inflight) == slots:
+                        flt.collect(inflight.pop(0), announced=True)
+                    k = f % slots
+                    inflight.append(flt.submit([src_arena[p][f % 8] for p in range(n)], dst=[dst_arena[p][k] for p in range(n)]))
+                while inflight:
+                    flt.collect(inflight.pop(0), announced=True)
+                out[f"ring{slots}_pinned_fps"] = round(a.frames / (time.perf_counter() - t0), 1)
+            finally:
+                for x in src_arena + dst_arena:
+                    unpin_host_array(x)
     print(json.dumps(out))
 
 
