@@ -194,8 +194,9 @@ __device__ __forceinline__ void box7(const unsigned (&S)[PXL], unsigned (&Bx)[PX
     for (int j = 0; j + 1 < PXL; ++j) Bx[j + 1] = Bx[j] - X(j - 3) + X(j + 4);
 }
 
-// Access to the scratch pools of the chroma coupling (see Mode).  A thread's slot of a pool row is two 8-byte chunks:
-// chunk 0 = the 8 smoothed bytes of its low-half strip, chunk 1 = those of its high-half strip.  A lane fetches each
+// Access to the scratch pools of the chroma coupling (see Mode).  A thread has two 8-byte chunks in a pool row:
+// chunk 0 = the 8 smoothed bytes of its low-half strip, chunk 1 = those of its high-half strip (all chunks 0 of the
+// row first, then all chunks 1).  A lane fetches each
 // half from the chunk of the thread that OWNS those columns (ghost lanes: the neighbouring wave's seam lanes; at the
 // wrap seam between strip NW-1 and strip NW the owner's columns sit in the OTHER half), so nothing is shuffled after
 // the load, and each half is stored / fetched only where the dependency cone (Args::cone_*) needs it.
@@ -264,7 +265,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
                                             PoolIO::RawPair& stale)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
-    if constexpr (MODE == kChroma) {
+    if constexpr (chroma_mode(MODE)) {
         io.finish(stale, D);
         // the stale row of the buffer after next is fetched into the registers this one has just left (two buffer steps
         // of lead, two loads in flight; the fence keeps the compiler from hoisting the load above the unpacking, which
@@ -309,7 +310,9 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
     if constexpr (has_pools(MODE)) {
         // the luma sweep skips the packing where no lane of the wave stores (rows past the hand-off, waves outside
         // the cone); the chroma sweep cannot afford the branch (registers) and lets the range check drop the stores
-        if (MODE == kChroma || rc.any_out) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
+        if constexpr (MODE != kChromaLast) {
+            if (MODE == kChroma || rc.any_out) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
+        }
     }
 }
 
@@ -324,7 +327,7 @@ struct Out {
 // Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
 // The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
 // in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
-__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 3 : 6; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : 6; }
 template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
@@ -382,7 +385,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
     // kChroma: the previous pass's row r+1 is fetched one buffer ahead of its use (HBM latency), and the
     // scheduler is kept from hoisting all nine fetches (their registers would spill).
     PoolIO::RawPair st0{}, st1{};  // even / odd buffers' stale rows in flight
-    if constexpr (MODE == kChroma) {
+    if constexpr (chroma_mode(MODE)) {
         st0 = io.issue(0, rc.r + 1, rc.vin_lo, rc.vin_hi);
         st1 = io.issue(1, rc.r + 1, rc.vin_lo, rc.vin_hi);
     }
@@ -457,7 +460,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 // The pool-coupled modes park six buffers' state in LDS and have room for ONE copy of the mailbox only: there a second
 // barrier (before publishing) makes sure every wave has taken the previous refresh out of it.  The other modes keep two
 // copies, alternating, and meet once per refresh.
-__host__ __device__ constexpr int mailbox_copies(int mode) { return has_pools(mode) ? 1 : 2; }
+__host__ __device__ constexpr int mailbox_copies(int mode) { return (has_pools(mode) && mode != kChromaLast) ? 1 : 2; }
 template <int NW, int COPIES>
 struct Mailbox {  // [copy][wave 0..NW-1][side][slot][72][2 halves] 16-bit entries in dynamic LDS
     unsigned short* h;
@@ -578,7 +581,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         const int pool_bytes = kBuffers * a.pool_rows * NW * 64 * 16;
         io.row_stride = NW * 64 * 16;
         io.buf_stride = a.pool_rows * io.row_stride;
-        if (MODE == kChroma)
+        if (chroma_mode(MODE))
             io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in ? a.pool_in + (int64_t)f * a.pool_frame_stride : nullptr), 0,
                                                        a.pool_in ? pool_bytes : 0, 0x00020000);
         io.rout = __builtin_amdgcn_make_buffer_rsrc(a.pool_out ? a.pool_out + (int64_t)f * a.pool_frame_stride : nullptr, 0,
@@ -595,10 +598,12 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             if (wave < NW - 1) t_lo = t_hi = (wave + 1) * 64 + GH + (lane - (64 - GH));
             else { t_lo = GH + (lane - (64 - GH)); c_lo = 1; }               // lo half <- strip NW (a high half)
         }
-        io.v_lo = t_lo * 16 + c_lo * 8;
-        io.v_hi = t_hi * 16 + c_hi * 8;
-        io.v_out_lo = real[0] ? tid * 16 : kOutOfRange;
-        io.v_out_hi = real[1] ? tid * 16 + 8 : kOutOfRange;
+        // a pool row is [chunk kind][thread][8 bytes]: the chunks of one kind lie side by side, so the lanes inside the
+        // cone write and read whole cache lines (interleaved with the other kind every line was half useful)
+        io.v_lo = c_lo * (NW * 64 * 8) + t_lo * 8;
+        io.v_hi = c_hi * (NW * 64 * 8) + t_hi * 8;
+        io.v_out_lo = real[0] ? tid * 8 : kOutOfRange;
+        io.v_out_hi = real[1] ? NW * 64 * 8 + tid * 8 : kOutOfRange;
     }
 
     // Does a half of this lane matter in pool row q (Args::cone_*)?  Column of the low half: 8 * lane + 480 * wave, the
@@ -612,7 +617,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
 
     const int nk = a.nk;
     const int nr = nk - 1;
-    const int sweep = MODE == kChroma ? a.sweep_rows : nr;
+    const int sweep = chroma_mode(MODE) ? a.sweep_rows : nr;
     const unsigned thr_key = (unsigned)((a.thr + 1) << 4) * 0x00010001u;
 
     Line L0, L1;
@@ -628,11 +633,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // A[1] = O[0] + P[1] = P[1] (pool row 0 is never written: zero); P[1] = stage-1 costs of the first
     // line pair, and outside the chroma region (kChroma) what the previous pass left in row 1
     unsigned A[kRegBuffers][PXL];
-    const bool first_lo = MODE == kChroma && a.rows_in >= 1 && in_cone(1, a.cone_in, 0);
-    const bool first_hi = MODE == kChroma && a.rows_in >= 1 && in_cone(1, a.cone_in, 1);
+    const bool first_lo = chroma_mode(MODE) && a.rows_in >= 1 && in_cone(1, a.cone_in, 0);
+    const bool first_hi = chroma_mode(MODE) && a.rows_in >= 1 && in_cone(1, a.cone_in, 1);
     auto init_A = [&](auto buf, unsigned (&Ab)[PXL]) {
         constexpr int B = decltype(buf)::value;
-        if constexpr (MODE == kChroma) {
+        if constexpr (chroma_mode(MODE)) {
             io.load(B, 1, first_lo ? io.v_lo : kOutOfRange, first_hi ? io.v_hi : kOutOfRange, Ab);
             if (nr > 0) {
 #pragma unroll
@@ -724,7 +729,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         rc.r = r;
         rc.vin_lo = rc.vin_hi = rc.vout = rc.vout_hi = kOutOfRange;
         rc.any_out = false;
-        if constexpr (MODE == kChroma) {
+        if constexpr (chroma_mode(MODE)) {
             const bool row_in = r + 1 <= a.rows_in;
             rc.vin_lo = (row_in && in_cone(r + 1, a.cone_in, 0)) ? io.v_lo : kOutOfRange;
             rc.vin_hi = (row_in && in_cone(r + 1, a.cone_in, 1)) ? io.v_hi : kOutOfRange;
@@ -800,7 +805,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         L1 = L0;
     }
     if (nr >= 1) step(nr, L1, L0, F{}, T{});
-    if constexpr (MODE == kChroma) {
+    if constexpr (chroma_mode(MODE)) {
         for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
     }
 
@@ -826,8 +831,8 @@ int fused_v3_waves(int sweep_w) { return (v3::virtual_waves_for(sweep_w / v3::PX
 // bytes of one scratch pool of one frame: [9][rows][threads][16]
 int64_t fused_v3_pool_bytes(int sweep_w, int rows) { return (int64_t)kBuffers * rows * fused_v3_waves(sweep_w) * 64 * 16; }
 
-// Slot of thread t: bytes 0..7 = the eight columns of its strip in the low halves (strip `wave`), bytes 8..15 = those of the
-// strip in the high halves (strip `wave + nw`), as PoolIO::store packs them.  Cells outside the dependency cone are
+// A pool row is [2 chunk kinds][threads][8 bytes]: kind 0 = the eight columns of the thread's strip in the low halves (strip
+// `wave`), kind 1 = those of its strip in the high halves (strip `wave + nw`), as PoolIO::store packs them.  Cells outside the dependency cone are
 // never written; `out` keeps what the caller put there.
 void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* out)
 {
@@ -841,7 +846,7 @@ void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* o
                 const int gl = vw == 0 ? lane : kFirst + kInner * (vw - 1) + (lane - GH);
                 const bool ghost = vw == 0 ? (nvw > 1 && lane >= 64 - GH) : (lane < GH || (lane >= 64 - GH && vw < nvw - 1));
                 if (vw >= nvw || ghost || gl >= nl) continue;
-                const uint8_t* d = bytes + (br * nt + t) * 16 + h * 8;
+                const uint8_t* d = bytes + br * nt * 16 + (int64_t)h * nt * 8 + t * 8;
                 uint8_t* o = out + br * sweep_w + gl * PXL;
                 for (int k = 0; k < PXL; ++k) o[k] = d[k];
             }
@@ -910,6 +915,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.cone_out = pool->cone_out;
     if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
     if (pool->mode == v3::kPadded) return launch_mode<v3::kPadded>(st, a, nframes);
+    if (!pool->pool_out) return launch_mode<v3::kChromaLast>(st, a, nframes);
     return launch_mode<v3::kChroma>(st, a, nframes);
 }
 

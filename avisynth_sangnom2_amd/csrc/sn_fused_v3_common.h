@@ -70,9 +70,12 @@ struct Args {
 // thread re-reads what the thread with the same columns wrote; ghost lanes read their owner's slot.
 //   kPadded     a plane narrower than its pool stride on a zero-filled pool (sn_config.fresh_pool): the sweep covers
 //               the whole stride, costs are zero in the padding columns, nothing is read back or left behind.
-enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2, kPadded = 3 };
-__host__ __device__ constexpr bool has_region(int mode) { return mode == kChroma || mode == kPadded; }  // lines narrower than the sweep
-__host__ __device__ constexpr bool has_pools(int mode) { return mode == kLumaSpill || mode == kChroma; }
+//   kChromaLast the last chroma sweep of a frame: kChroma that hands nothing on (8-bit sweep only: no packing of stores
+//               that would all be dropped)
+enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2, kPadded = 3, kChromaLast = 4 };
+__host__ __device__ constexpr bool chroma_mode(int mode) { return mode == kChroma || mode == kChromaLast; }
+__host__ __device__ constexpr bool has_region(int mode) { return chroma_mode(mode) || mode == kPadded; }  // lines narrower than the sweep
+__host__ __device__ constexpr bool has_pools(int mode) { return mode == kLumaSpill || chroma_mode(mode); }
 
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
