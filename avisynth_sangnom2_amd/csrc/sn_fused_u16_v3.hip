@@ -192,6 +192,7 @@ struct RowCtx {
     int r;
     int vin;  // kChroma: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
     int vout;
+    bool any_out;  // wave-uniform: some lane of this wave stores in this row
 };
 
 template <int BUF, int MODE, bool S1>
@@ -211,10 +212,12 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             A[j] = S1 ? cost_acc<BUF>(n, nn, j, O[j]) : O[j];
             kmin[j] = umin(kmin[j], key);
         }
-        if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
+        if constexpr (has_pools(MODE)) {
+            if (rc.any_out) io.store(BUF, rc.r, rc.vout, O);  // the luma sweep packs its hand-off only where a lane stores
+        }
         return;
     }
-    if constexpr (MODE == kChroma) {
+    if constexpr (chroma_mode(MODE)) {
         io.finish(stale, D);
         if constexpr (S1) {
 #pragma unroll
@@ -239,13 +242,14 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
         A[j] = O[j] + D[j];
         kmin[j] = umin(kmin[j], t | rank_of<BUF>());
     }
-    if constexpr (has_pools(MODE)) io.store(BUF, rc.r, rc.vout, O);
+    if constexpr (MODE == kChroma) io.store(BUF, rc.r, rc.vout, O);  // (kChromaLast hands nothing on)
 }
 
 // A wave of a chroma sweep whose columns all lie outside the chroma region has no lines, no stage 1 and no stage 3: the
 // cost of the next row is what the previous pass left there, nothing else (see stale_wave_sweep).
 template <int BUF>
-__device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], const u32x4& stale, const LaneRole& role, const PoolIO& io, int r, int vout)
+__device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], const u32x4& stale, const LaneRole& role, const PoolIO& io, int r, int vout,
+                                                  bool vout_any)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
     io.finish(stale, D);
@@ -258,7 +262,7 @@ __device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], const u32x
         O[j] = (Bx[j] >> 4) & kVal;  // (sum / 16) wraps to uint16_t, SangNom2.cpp:152
         A[j] = O[j] + D[j];
     }
-    io.store(BUF, r, vout, O);
+    if (vout_any) io.store(BUF, r, vout, O);
 }
 
 __host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 6; }
@@ -313,10 +317,10 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 #pragma unroll
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
     u32x4 st0{}, st1{};
-    if constexpr (MODE == kChroma) st0 = io.issue(0, rc.r + 1, rc.vin);
+    if constexpr (chroma_mode(MODE)) st0 = io.issue(0, rc.r + 1, rc.vin);
     auto run = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
-        if constexpr (MODE == kChroma) {
+        if constexpr (chroma_mode(MODE)) {
             if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.vin);
         }
         if constexpr (B < reg_buffers(MODE)) {
@@ -327,7 +331,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
             buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st0);
             pk.store_A(tid, B, t);
         }
-        if constexpr (MODE == kChroma) st0 = st1;
+        if constexpr (chroma_mode(MODE)) st0 = st1;
     };
     run(std::integral_constant<int, 0>{});
     run(std::integral_constant<int, 1>{});
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         const int pool_bytes = kBuffers * a.pool_rows * NT * 16;
         io.row_stride = NT * 16;
         io.buf_stride = a.pool_rows * io.row_stride;
-        if (MODE == kChroma)
+        if (chroma_mode(MODE))
             io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in ? a.pool_in + (int64_t)f * a.pool_frame_stride : nullptr), 0,
                                                        a.pool_in ? pool_bytes : 0, 0x00020000);
         io.rout = __builtin_amdgcn_make_buffer_rsrc(a.pool_out ? a.pool_out + (int64_t)f * a.pool_frame_stride : nullptr, 0,
@@ -493,10 +497,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
 
     const int nk = a.nk;
     const int nr = nk - 1;
-    const int sweep = MODE == kChroma ? a.sweep_rows : nr;
+    const int sweep = chroma_mode(MODE) ? a.sweep_rows : nr;
     const unsigned thr_key = (unsigned)(a.thr + 1) << 4;
 
-    if constexpr (MODE == kChroma) {
+    if constexpr (chroma_mode(MODE)) {
         // Waves entirely to the right of the chroma region (columns 480 * wave and up; with 4:2:0 the right half of the
         // workgroup) only re-smooth what the previous pass left: no lines, no costs, no ladder.  All nine buffers' state
         // stays in registers, the stale rows are fetched a whole row ahead, and the wave LEAVES once every column from
@@ -529,15 +533,16 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
                     }
                 }
                 const int vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
-                stale_buffer_step<0>(As[0], cur[0], role, io, r, vout);
-                stale_buffer_step<1>(As[1], cur[1], role, io, r, vout);
-                stale_buffer_step<2>(As[2], cur[2], role, io, r, vout);
-                stale_buffer_step<3>(As[3], cur[3], role, io, r, vout);
-                stale_buffer_step<4>(As[4], cur[4], role, io, r, vout);
-                stale_buffer_step<5>(As[5], cur[5], role, io, r, vout);
-                stale_buffer_step<6>(As[6], cur[6], role, io, r, vout);
-                stale_buffer_step<7>(As[7], cur[7], role, io, r, vout);
-                stale_buffer_step<8>(As[8], cur[8], role, io, r, vout);
+                const bool vout_any = __builtin_amdgcn_readfirstlane(__any(vout != kOutOfRange) ? 1 : 0) != 0;
+                stale_buffer_step<0>(As[0], cur[0], role, io, r, vout, vout_any);
+                stale_buffer_step<1>(As[1], cur[1], role, io, r, vout, vout_any);
+                stale_buffer_step<2>(As[2], cur[2], role, io, r, vout, vout_any);
+                stale_buffer_step<3>(As[3], cur[3], role, io, r, vout, vout_any);
+                stale_buffer_step<4>(As[4], cur[4], role, io, r, vout, vout_any);
+                stale_buffer_step<5>(As[5], cur[5], role, io, r, vout, vout_any);
+                stale_buffer_step<6>(As[6], cur[6], role, io, r, vout, vout_any);
+                stale_buffer_step<7>(As[7], cur[7], role, io, r, vout, vout_any);
+                stale_buffer_step<8>(As[8], cur[8], role, io, r, vout, vout_any);
                 if (r < sweep && r % K == 0) {
                     if (pub_right || pub_left) {
                         unsigned* to = pub_right ? mb.at(((r + 1) / K) & 1, wave + 1, 0, slot) : mb.at(((r + 1) / K) & 1, wave - 1, 1, slot);
@@ -567,13 +572,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     unpack(L1, q1, role);
     parked.park(tid, L0);
 
-    const bool first_in = MODE == kChroma && a.rows_in >= 1 && in_cone(1, a.cone_in);
+    const bool first_in = chroma_mode(MODE) && a.rows_in >= 1 && in_cone(1, a.cone_in);
 
     // A[1] = O[0] + P[1] = P[1]
     unsigned A[RB][PXL];
     auto init_A = [&](auto buf, unsigned (&Ab)[PXL]) {
         constexpr int B = decltype(buf)::value;
-        if constexpr (MODE == kChroma) {
+        if constexpr (chroma_mode(MODE)) {
             io.finish(io.issue(B, 1, first_in ? io.v_a : kOutOfRange), Ab);
             if (nr > 0) {
 #pragma unroll
@@ -655,8 +660,12 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         RowCtx rc;
         rc.r = r;
         rc.vin = rc.vout = kOutOfRange;
-        if constexpr (MODE == kChroma) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
-        if constexpr (has_pools(MODE)) rc.vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
+        if constexpr (chroma_mode(MODE)) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+        rc.any_out = false;
+        if constexpr (has_pools(MODE)) {
+            rc.vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
+            rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
+        }
         pending = row_step<MODE, S1, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c
         if (r < sweep && r % K == 0) {
@@ -689,7 +698,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         step(nr, L1, L0, F{}, T{});
         put(out_row, pending);
     }
-    if constexpr (MODE == kChroma) {
+    if constexpr (chroma_mode(MODE)) {
         for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
     }
 
@@ -787,6 +796,7 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.cone_out = pool->cone_out;
     if (pool->mode == v3c::kLumaSpill) return w16::launch_mode<v3c::kLumaSpill>(st, a, nframes);
     if (pool->mode == v3c::kPadded) return w16::launch_mode<v3c::kPadded>(st, a, nframes);
+    if (!pool->pool_out) return w16::launch_mode<v3c::kChromaLast>(st, a, nframes);
     return w16::launch_mode<v3c::kChroma>(st, a, nframes);
 }
 
