@@ -162,7 +162,7 @@ __device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL],
     }
 }
 
-constexpr int kRegBuffers = 2;  // buffers 0, 1 keep A in VGPRs, 2..8 in LDS between their steps (no scratch spills)
+constexpr int kRegBuffers = 6;  // buffers 0..5 keep A in VGPRs, 6..8 in LDS between their steps (built without the SLP vectoriser the sweep needs ~212 VGPRs with two: six fit without scratch, seven touch the 256 limit)
 
 template <int NT>
 struct Parked {
