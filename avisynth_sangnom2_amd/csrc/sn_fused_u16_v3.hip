@@ -265,7 +265,7 @@ __device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], const u32x
     if (vout_any) io.store(BUF, r, vout, O);
 }
 
-__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 6; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 9; }
 
 template <int NT, int RB>
 struct Parked {

@@ -46,7 +46,7 @@ namespace sn {
 namespace v3 {
 
 using namespace v3c;
-constexpr int kMaxWaves = 8;         // physical waves per workgroup (16 virtual wavefronts, 7680 pixels)
+[[maybe_unused]] constexpr int kMaxWaves = 8;         // physical waves per workgroup (16 virtual wavefronts, 7680 pixels)
 constexpr unsigned kLo = 0x0000ffffu, kHi = 0xffff0000u, kByte = 0x00ff00ffu;
 
 // One kept line: P[i] = pixel (x0 - 3 + i) of both strips, F / B = the two SangNom values per pixel
@@ -327,7 +327,7 @@ struct Out {
 // Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
 // The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
 // in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
-__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : 6; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : 8; }
 template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
@@ -820,6 +820,37 @@ static int virtual_waves_for(int nl) { return strips_for(nl); }
 
 }  // namespace v3
 
+// This file is compiled twice (csrc/Makefile).  The sweeps of planes on their own (kPlain, kPadded) go into an object
+// of their own, built with -mllvm -amdgpu-sched-strategy=max-ilp: +1.7 % on them, but that scheduler makes the
+// pool-coupled modes (which live at the register limit) spill, so those keep the default one.
+template <int MODE>
+static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
+{
+    const int g = v3c::group_of(a.nw);
+    const int lds = v3::lds_bytes(a.nw, MODE) * g;
+    hipError_t e = hipSuccess;
+#define SN_LAUNCH(NW)                                                                                              \
+    case NW:                                                                                                       \
+        if (lds > 64 * 1024)                                                                                       \
+            e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((v3::k_fused_u8_v3<NW, MODE>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a); \
+        break;
+    switch (a.nw) {
+        SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef SN_LAUNCH
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+#ifdef SN_TU_PLAIN
+hipError_t launch_fused_u8_v3_plain(hipStream_t st, const v3c::Args& a, int nframes, int mode)
+{
+    return mode == v3::kPadded ? launch_mode<v3::kPadded>(st, a, nframes) : launch_mode<v3::kPlain>(st, a, nframes);
+}
+#else
+
 bool fused_v3_plane_ok(int w)
 {
     if (w % 32 != 0) return false;
@@ -852,27 +883,6 @@ void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* o
             }
 }
 
-template <int MODE>
-static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
-{
-    const int g = v3c::group_of(a.nw);
-    const int lds = v3::lds_bytes(a.nw, MODE) * g;
-    hipError_t e = hipSuccess;
-#define SN_LAUNCH(NW)                                                                                              \
-    case NW:                                                                                                       \
-        if (lds > 64 * 1024)                                                                                       \
-            e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((v3::k_fused_u8_v3<NW, MODE>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a); \
-        break;
-    switch (a.nw) {
-        SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
-    default: return hipErrorInvalidValue;
-    }
-#undef SN_LAUNCH
-    if (e != hipSuccess) return e;
-    return hipGetLastError();
-}
-
 // pool == nullptr: a plane on its own (kPlain).  Otherwise pool->mode selects kLumaSpill / kChroma and
 // pool->sweep_w is the luma width the sweep covers (p describes the plane being interpolated).
 hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool)
@@ -900,7 +910,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
 
     a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
     a.nframes = nframes;
-    if (!pool) return launch_mode<v3::kPlain>(st, a, nframes);
+    if (!pool) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPlain);
     a.pool_in = pool->pool_in;
     a.pool_out = pool->pool_out;
     a.pool_frame_stride = pool->frame_stride;
@@ -914,9 +924,11 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.cone_in = pool->cone_in;
     a.cone_out = pool->cone_out;
     if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
-    if (pool->mode == v3::kPadded) return launch_mode<v3::kPadded>(st, a, nframes);
+    if (pool->mode == v3::kPadded) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPadded);
     if (!pool->pool_out) return launch_mode<v3::kChromaLast>(st, a, nframes);
     return launch_mode<v3::kChroma>(st, a, nframes);
 }
+
+#endif  // SN_TU_PLAIN
 
 }  // namespace sn

@@ -195,4 +195,8 @@ __device__ __forceinline__ void store_b128(const u32x4& d, __amdgpu_buffer_rsrc_
 inline int strips_for(int nl) { return nl <= 64 ? 1 : 1 + (nl - kFirst + kInner - 1) / kInner; }
 
 }  // namespace v3c
+
+// sn_fused_u8_v3.hip compiled with -DSN_TU_PLAIN: the 8-bit sweeps of planes on their own (mode kPlain / kPadded)
+hipError_t launch_fused_u8_v3_plain(hipStream_t st, const v3c::Args& a, int nframes, int mode);
+
 }  // namespace sn
