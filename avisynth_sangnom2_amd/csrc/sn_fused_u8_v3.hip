@@ -327,7 +327,7 @@ struct Out {
 // Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
 // The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
 // in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
-__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : 8; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : 9; }
 template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
@@ -402,14 +402,23 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
         }
     };
     run(std::integral_constant<int, 0>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 1>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 2>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 3>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 4>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 5>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 6>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 7>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
     run(std::integral_constant<int, 8>{});
+    if constexpr (MODE == kPlain) __builtin_amdgcn_sched_barrier(0);
 
     Out o{};
     if constexpr (!S3) return o;
