@@ -374,13 +374,27 @@ static int create_impl(const sn_config* cfg, Context* c)
         const int nr_c = c->plane_h_out(1) / 2 - 1;
         const int reach = nr_c + 2 < c->bh - 1 ? nr_c + 2 : c->bh - 1;
         c->fpool_rows = reach + 1;
-        c->fpool_frame_bytes = cfg->bytes_per_sample == 2 ? sn::fused_u16_pool_bytes(cfg->width, c->fpool_rows)
-                                                          : sn::fused_v3_pool_bytes(cfg->width, c->fpool_rows);
-        c->fslots = fit(2 * c->fpool_frame_bytes);  // fused420 implies history-free (fused_eligible)
+        c->fpool_frame_bytes = cfg->bytes_per_sample == 4   ? sn::fused_f32_pool_bytes(cfg->width, c->fpool_rows)
+                               : cfg->bytes_per_sample == 2 ? sn::fused_u16_pool_bytes(cfg->width, c->fpool_rows)
+                                                            : sn::fused_v3_pool_bytes(cfg->width, c->fpool_rows);
         // a chunk is three launches of one workgroup per frame: whole rounds of resident workgroups
         // (two waves per SIMD, 256 CUs) leave no partly filled round at the end of each launch
-        const int nw = cfg->bytes_per_sample == 2 ? sn::fused_u16_waves(cfg->width) : sn::fused_v3_waves(cfg->width);
+        const int nw = cfg->bytes_per_sample == 4   ? sn::fused_f32_waves(cfg->width)
+                       : cfg->bytes_per_sample == 2 ? sn::fused_u16_waves(cfg->width)
+                                                    : sn::fused_v3_waves(cfg->width);
         const int round = 256 * (8 / nw);
+        c->fslots = fit(2 * c->fpool_frame_bytes);  // fused420 implies history-free (fused_eligible)
+        if (c->fslots < round && !getenv("SN_SCRATCH_BUDGET_MB")) {
+            // wide float frames: a chunk below one round leaves compute units idle in every launch, so the hand-off
+            // pools may take up to a quarter of the device's memory to reach one
+            size_t free_b = 0, total_b = 0;
+            SN_HIP(c, hipMemGetInfo(&free_b, &total_b));
+            const int64_t cap = (int64_t)(total_b / 4 < free_b / 2 ? total_b / 4 : free_b / 2) / (2 * c->fpool_frame_bytes);
+            const int64_t want = c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth;
+            int64_t n = cap < round ? cap : round;
+            if (n > want) n = want;
+            if (n > c->fslots) c->fslots = (int)n;
+        }
         if (c->fslots > round) c->fslots -= c->fslots % round;
         for (int i = 0; i < 2; ++i) {
             SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->fslots));
@@ -499,7 +513,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     };
 
     auto launch_plain_fused = [&](const sn::PlaneArgs& a, int p, int m) -> hipError_t {
-        if (c->cfg.bytes_per_sample == 4) return sn::launch_fused_f32_v3(st, a, c->threshold(p), m);
+        if (c->cfg.bytes_per_sample == 4) return sn::launch_fused_f32_v3(st, a, c->threshold(p), m, nullptr);
         if (c->cfg.bytes_per_sample == 2) return sn::launch_fused_u16_v3(st, a, c->threshold(p), m, nullptr);
         return sn::launch_fused_u8_v3(st, a, c->threshold(p), m, nullptr);
     };
@@ -517,7 +531,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
                     fp.sweep_w = c->plane_pool[p].stride_e;
                     fp.pool_rows = 1;
                     fp.sweep_rows = a.h_out / 2 - 1;
-                    if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, fp.sweep_w));
+                    if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, &fp));
                     else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
                     else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp));
                 } else {
@@ -572,7 +586,8 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
                     fp.rows_out = p == 1 ? sweep_u : 0;
                 }
                 const sn::PlaneArgs a = frames_from(pa[p], i);
-                if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), m, &fp));
+                if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), m, &fp));
+                else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), m, &fp));
                 else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), m, &fp));
             }
         }
@@ -1021,7 +1036,8 @@ int sn_debug_read_coupled_rows(sn_context* h, int32_t which, void* host_dst, siz
     SN_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<uint32_t> raw((size_t)c->fpool_frame_bytes / 4);
     SN_HIP(c, hipMemcpy(raw.data(), c->fpool[which], (size_t)c->fpool_frame_bytes, hipMemcpyDeviceToHost));
-    if (c->cfg.bytes_per_sample == 2) sn::fused_u16_pool_unpack(raw.data(), c->cfg.width, c->fpool_rows, static_cast<uint16_t*>(host_dst));
+    if (c->cfg.bytes_per_sample == 4) sn::fused_f32_pool_unpack(raw.data(), c->cfg.width, c->fpool_rows, static_cast<float*>(host_dst));
+    else if (c->cfg.bytes_per_sample == 2) sn::fused_u16_pool_unpack(raw.data(), c->cfg.width, c->fpool_rows, static_cast<uint16_t*>(host_dst));
     else sn::fused_v3_pool_unpack(raw.data(), c->cfg.width, c->fpool_rows, static_cast<uint8_t*>(host_dst));
     return SN_OK;
 }

@@ -1,4 +1,5 @@
-// sn_fused_f32_v3.hip -- the fused sweep for 32-bit float samples (Y32, YUV444PS; no chroma coupling).
+// sn_fused_f32_v3.hip -- the fused sweep for 32-bit float samples (Y32, YUV444PS; 4:2:0 / 4:2:2 float clips through
+// the same hand-off modes as the integer sweeps, see Mode in sn_fused_v3_common.h and the stale-wave path below).
 //
 // Same structure as sn_fused_u16_v3.hip (read the header of sn_fused_u8_v3.hip for the algorithm and the
 // exactness argument): one workgroup sweeps one plane top to bottom, a lane owns 8 consecutive pixels of
@@ -21,6 +22,8 @@
 #include <type_traits>
 
 #include "sn_fused_v3_common.h"
+
+#include <cstring>
 
 namespace sn {
 namespace f32 {
@@ -46,7 +49,8 @@ struct LaneRole {
     bool first;      // lane owns column 0
     bool last;       // lane owns the last column of the sweep
     bool line_last;  // lane owns the last column of the source lines (PADDED: region_w - 1)
-    float inside;    // PADDED: 1 where the lane's columns belong to the plane, 0 in the padding
+    float inside;    // kPadded: 1 where the lane's columns belong to the plane, 0 in the padding
+    bool inside_b;   // chroma modes: the lane's columns lie inside the chroma region (else: stale values instead of costs)
     unsigned first_mask, last_mask;  // all ones where first / last
 };
 
@@ -138,33 +142,120 @@ __device__ __forceinline__ void box7(const float (&S)[PXL], float (&Bx)[PXL], co
         Bx[j] = (((((X[j] + X[j + 1]) + X[j + 2]) + X[j + 3]) + X[j + 4]) + X[j + 5]) + X[j + 6];
 }
 
-// PADDED: a plane narrower than its pool stride on a zero-filled pool (sn_config.fresh_pool, see Mode kPadded in
-// sn_fused_v3_common.h): costs are zero in the padding columns -- a multiplication by 1 or 0 (costs are finite and
-// not negative, so that is exact).
-template <int BUF, bool S1, bool PADDED>
-__device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL], unsigned (&rank)[PXL], const Line& n,
-                                            const Line& nn, const LaneRole& role)
+// Scratch pools of the chroma coupling (Mode): [buffer][row][thread][8 floats] -- a thread re-reads what the thread with the
+// same columns wrote (ghost lanes read their owner's slot); only slots inside the dependency cone (Args::cone_*) move.
+struct PoolIO {
+    __amdgpu_buffer_rsrc_t rin, rout;
+    int v_a;    // slot this lane reads: its own, or its owner's for ghost lanes
+    int v_out;  // slot this lane writes
+    int row_stride, buf_stride;
+    struct RawPair {
+        u32x4 a, b;
+    };
+    __device__ __forceinline__ RawPair issue(int b, int row, int va) const  // va: v_a or kOutOfRange (-> zeros)
+    {
+        const int soff = b * buf_stride + row * row_stride;
+        RawPair q;
+        q.a = __builtin_amdgcn_raw_buffer_load_b128(rin, va, soff, 0);
+        q.b = __builtin_amdgcn_raw_buffer_load_b128(rin, va, soff + 16, 0);
+        return q;
+    }
+    __device__ __forceinline__ void finish(const RawPair& q, float (&P)[PXL]) const
+    {
+        P[0] = flt(q.a.x); P[1] = flt(q.a.y); P[2] = flt(q.a.z); P[3] = flt(q.a.w);
+        P[4] = flt(q.b.x); P[5] = flt(q.b.y); P[6] = flt(q.b.z); P[7] = flt(q.b.w);
+    }
+    __device__ __forceinline__ void store(int b, int row, int vout, const float (&O)[PXL]) const
+    {
+        u32x4 lo, hi;
+        lo.x = bits(O[0]); lo.y = bits(O[1]); lo.z = bits(O[2]); lo.w = bits(O[3]);
+        hi.x = bits(O[4]); hi.y = bits(O[5]); hi.z = bits(O[6]); hi.w = bits(O[7]);
+        const int soff = b * buf_stride + row * row_stride;
+        store_b128(lo, rout, vout, soff);
+        store_b128(hi, rout, vout, soff + 16);
+    }
+};
+
+struct RowCtx {
+    int r;
+    int vin;       // chroma modes: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
+    int vout;      // voffset of this row's stores (out of range: not kept)
+    bool any_out;  // wave-uniform: some lane of this wave stores in this row
+};
+
+// the order in which a row visits the buffers: lowest rung of the ladder first (a later buffer with an equal cost takes over)
+__host__ __device__ constexpr int visit(int i)
 {
-    float D[PXL], S[PXL], Bx[PXL];
+    constexpr int o[9] = {0, 8, 1, 7, 2, 6, 3, 5, 4};
+    return o[i];
+}
+
+// kPadded: a plane narrower than its pool stride on a zero-filled pool (sn_config.fresh_pool): costs are zero in the padding
+// columns -- a multiplication by 1 or 0 (costs are finite and not negative, so that is exact).  Chroma modes: outside the
+// chroma region the cost of the next row is what the previous pass left there (`stale`, fetched one buffer ahead).
+template <int I, bool S1, int MODE>
+__device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL], unsigned (&rank)[PXL], const Line& n,
+                                            const Line& nn, const LaneRole& role, const PoolIO& io, const RowCtx& rc, PoolIO::RawPair& stale)
+{
+    constexpr int BUF = visit(I);
+    float D[PXL], S[PXL], Bx[PXL], O[PXL];
+    if constexpr (chroma_mode(MODE)) {
+        io.finish(stale, D);
+        __builtin_amdgcn_sched_barrier(0);  // the next fetch goes into the registers this one has just left
+        if constexpr (I + 1 < kBuffers) stale = io.issue(visit(I + 1), rc.r + 1, rc.vin);
+        if constexpr (S1) {
 #pragma unroll
-    for (int j = 0; j < PXL; ++j) D[j] = S1 ? (PADDED ? cost<BUF>(n, nn, j) * role.inside : cost<BUF>(n, nn, j)) : 0.0f;
+            for (int j = 0; j < PXL; ++j) D[j] = role.inside_b ? cost<BUF>(n, nn, j) : D[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) D[j] = S1 ? (MODE == kPadded ? cost<BUF>(n, nn, j) * role.inside : cost<BUF>(n, nn, j)) : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < PXL; ++j) S[j] = A[j] + D[j];  // (O[r-1] + D[r]) + D[r+1]
     if (role.edge_wave) box7<true>(S, Bx, role);
     else box7<false>(S, Bx, role);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        const float O = Bx[j] * 0.0625f;
-        A[j] = O + D[j];
-        const bool le = O <= vmin[j];
-        vmin[j] = le ? O : vmin[j];
+        O[j] = Bx[j] * 0.0625f;
+        A[j] = O[j] + D[j];
+        const bool le = O[j] <= vmin[j];
+        vmin[j] = le ? O[j] : vmin[j];
         rank[j] = le ? rank_of<BUF>() : rank[j];
+    }
+    if constexpr (MODE == kLumaSpill) {
+        if (rc.any_out) io.store(BUF, rc.r, rc.vout, O);  // packed only where a lane of the wave stores
+    } else if constexpr (MODE == kChroma) {
+        io.store(BUF, rc.r, rc.vout, O);
     }
 }
 
-constexpr int kRegBuffers = 6;  // buffers 0..5 keep A in VGPRs, 6..8 in LDS between their steps (built without the SLP vectoriser the sweep needs ~212 VGPRs with two: six fit without scratch, seven touch the 256 limit)
+// A wave of a chroma sweep whose columns all lie outside the chroma region: no lines, no stage 1, no stage 3 (as in
+// sn_fused_u16_v3.hip: stale_wave_sweep).
+template <int BUF>
+__device__ __forceinline__ void stale_buffer_step(float (&A)[PXL], const PoolIO::RawPair& stale, const LaneRole& role, const PoolIO& io, int r,
+                                                  int vout, bool vout_any)
+{
+    float D[PXL], S[PXL], Bx[PXL], O[PXL];
+    io.finish(stale, D);
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) S[j] = A[j] + D[j];
+    if (role.edge_wave) box7<true>(S, Bx, role);
+    else box7<false>(S, Bx, role);
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) {
+        O[j] = Bx[j] * 0.0625f;
+        A[j] = O[j] + D[j];
+    }
+    if (vout_any) io.store(BUF, r, vout, O);
+}
 
-template <int NT>
+// buffers 0 .. reg_buffers-1 keep A in VGPRs, the others in LDS between their steps (no scratch spills).  Built without the
+// SLP vectoriser the plain sweep needs ~212 VGPRs with two: six fit without scratch, seven touch the 256 limit; the
+// pool-coupled modes carry the stale row in flight and the row to store, so they keep fewer.
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kPadded ? 4 : 6; }
+
+template <int NT, int kRegBuffers>
 struct Parked {
     uint4* v;  // [4][NT]: the 14 pixels of the parked line (its SangNom values are recomputed: LDS is the scarcer store)
     uint4* a;  // [9 - kRegBuffers][2][NT]
@@ -201,10 +292,12 @@ struct Out {
     u32x4 lo, hi;  // 8 interpolated float pixels
 };
 
-template <bool S1, bool PADDED, int NT>
-__device__ __forceinline__ Out row_step(float (&A)[kRegBuffers][PXL], const Parked<NT>& pk, int tid, const Line& n,
-                                        const Line& nn, const LaneRole& role, float aaf)
+// S3: the row has an interpolated line (stage 3); a chroma sweep covers rows below its plane without one.
+template <bool S1, bool S3, int MODE, int NT>
+__device__ __forceinline__ Out row_step(float (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk, int tid, const Line& n,
+                                        const Line& nn, const LaneRole& role, float aaf, const PoolIO& io, const RowCtx& rc)
 {
+    constexpr int kRegBuffers = reg_buffers(MODE);
     float vmin[PXL];
     unsigned rank[PXL];
 #pragma unroll
@@ -212,28 +305,32 @@ __device__ __forceinline__ Out row_step(float (&A)[kRegBuffers][PXL], const Park
         vmin[j] = __builtin_inff();
         rank[j] = 0u;
     }
-    auto run = [&](auto buf) {
-        constexpr int B = decltype(buf)::value;
+    PoolIO::RawPair stale{};
+    if constexpr (chroma_mode(MODE)) stale = io.issue(visit(0), rc.r + 1, rc.vin);
+    auto run = [&](auto idx) {
+        constexpr int I = decltype(idx)::value;
+        constexpr int B = visit(I);
         if constexpr (B < kRegBuffers) {
-            buffer_step<B, S1, PADDED>(A[B], vmin, rank, n, nn, role);
+            buffer_step<I, S1, MODE>(A[B], vmin, rank, n, nn, role, io, rc, stale);
         } else {
             float t[PXL];
             pk.load_A(tid, B, t);
-            buffer_step<B, S1, PADDED>(t, vmin, rank, n, nn, role);
+            buffer_step<I, S1, MODE>(t, vmin, rank, n, nn, role, io, rc, stale);
             pk.store_A(tid, B, t);
         }
     };
-    // lowest rung of the ladder first: a later buffer with an equal cost takes over
     run(std::integral_constant<int, 0>{});
-    run(std::integral_constant<int, 8>{});
     run(std::integral_constant<int, 1>{});
-    run(std::integral_constant<int, 7>{});
     run(std::integral_constant<int, 2>{});
-    run(std::integral_constant<int, 6>{});
     run(std::integral_constant<int, 3>{});
-    run(std::integral_constant<int, 5>{});
     run(std::integral_constant<int, 4>{});
+    run(std::integral_constant<int, 5>{});
+    run(std::integral_constant<int, 6>{});
+    run(std::integral_constant<int, 7>{});
+    run(std::integral_constant<int, 8>{});
 
+    Out o{};
+    if constexpr (!S3) return o;
     Line c;
     pk.unpark(tid, c);
     unsigned v[PXL];
@@ -256,7 +353,6 @@ __device__ __forceinline__ Out row_step(float (&A)[kRegBuffers][PXL], const Park
         const unsigned r = bfi(m3, a89, c0);
         v[j] = bits(flt(r) * 0.5f);  // (a + b) * 0.5, SangNom2.cpp:52-58
     }
-    Out o;
     o.lo.x = v[0]; o.lo.y = v[1]; o.lo.z = v[2]; o.lo.w = v[3];
     o.hi.x = v[4]; o.hi.y = v[5]; o.hi.z = v[6]; o.hi.w = v[7];
     return o;
@@ -274,22 +370,24 @@ struct Mailbox {
     }
 };
 
-__host__ __device__ constexpr int lds_bytes(int nw)
+__host__ __device__ constexpr int lds_bytes(int nw, int mode)
 {
-    return (4 + (kBuffers - kRegBuffers) * 2) * 16 * nw * 64 + 2 * (2 * nw - 2) * GH * kBuffers * PXL * 4;
+    return (4 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + 2 * (2 * nw - 2) * GH * kBuffers * PXL * 4;
 }
 
-template <int NW, bool PADDED>
+template <int NW, int MODE>
 __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args a, float aaf)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int NT = NW * 64;
+    constexpr int kRegBuffers = reg_buffers(MODE);
+    constexpr bool PADDED = MODE == kPadded;
     const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / (NW * 64);
     const int f_raw = (int)blockIdx.x * group_of(NW) + sub;
     const int f = f_raw < a.nframes ? f_raw : a.nframes - 1;  // see sn_fused_u16_v3.hip
     const int tid = (int)threadIdx.x - sub * (NW * 64);
-    Parked<NT> parked;
-    parked.v = reinterpret_cast<uint4*>(lds_raw + sub * lds_bytes(NW));
+    Parked<NT, kRegBuffers> parked;
+    parked.v = reinterpret_cast<uint4*>(lds_raw + sub * lds_bytes(NW, MODE));
     parked.a = parked.v + 4 * NT;
     Mailbox<NW> mb;
     mb.h = reinterpret_cast<unsigned*>(parked.a + (kBuffers - kRegBuffers) * 2 * NT);
@@ -308,7 +406,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     const bool live = gl < a.nl;
     const bool real = live && !ghost;
     const int x0 = gl * PXL;
-    const int line_w = PADDED ? a.region_w : a.w;  // width of the source / destination plane
+    const int line_w = has_region(MODE) ? a.region_w : a.w;  // width of the source / destination plane
     const bool line_live = live && x0 < line_w;
     const bool line_real = real && x0 < line_w;
     LaneRole role;
@@ -316,6 +414,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     role.last = live && gl == a.nl - 1;
     role.line_last = line_live && x0 + PXL == line_w;
     role.inside = line_live ? 1.0f : 0.0f;
+    role.inside_b = line_live;
     role.first_mask = role.first ? 0xffffffffu : 0u;
     role.last_mask = role.last ? 0xffffffffu : 0u;
     role.edge_wave = __builtin_amdgcn_readfirstlane(__any((int)(role.first || role.last || role.line_last)) ? 1 : 0) != 0;
@@ -347,8 +446,96 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         store_b128(o.hi, rd, vstore, row_off + 16);
     };
 
+    // scratch pools of the chroma coupling
+    PoolIO io{};
+    if constexpr (has_pools(MODE)) {
+        const int pool_bytes = kBuffers * a.pool_rows * NT * 32;
+        io.row_stride = NT * 32;
+        io.buf_stride = a.pool_rows * io.row_stride;
+        if (chroma_mode(MODE))
+            io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in ? a.pool_in + (int64_t)f * a.pool_frame_stride : nullptr), 0,
+                                                       a.pool_in ? pool_bytes : 0, 0x00020000);
+        io.rout = __builtin_amdgcn_make_buffer_rsrc(a.pool_out ? a.pool_out + (int64_t)f * a.pool_frame_stride : nullptr, 0,
+                                                    a.pool_out ? pool_bytes : 0, 0x00020000);
+        int ta = tid;  // ghost lanes read the slot of the thread that owns their columns
+        if (lane < GH && wave > 0) ta = (wave - 1) * 64 + (64 - 2 * GH) + lane;
+        if (lane >= 64 - GH && wave < NW - 1) ta = (wave + 1) * 64 + GH + (lane - (64 - GH));
+        io.v_a = ta * 32;
+        io.v_out = real ? tid * 32 : kOutOfRange;
+    }
+    // Does this lane's slot of pool row q matter (Args::cone_*)?  Its first column is 8 * lane + 480 * wave.
+    auto in_cone = [&](int q, int extra) -> bool {
+        const int lim = a.cone_w + 3 * (a.cone_nr - q + 2) + extra;
+        const int cols = lim < a.w ? lim : a.w;
+        const int xa = (lane << 3) + wave * (kInner * PXL);
+        return xa < cols && (q > a.cone_nr || xa + PXL > a.cone_w);
+    };
+
+    // seam exchange: lanes 60, 61 feed the next wave's left ghosts, lanes 2, 3 the previous wave's right ghosts
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < NW - 1;
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
     const int nk = a.nk;
     const int nr = nk - 1;
+    const int sweep = chroma_mode(MODE) ? a.sweep_rows : nr;
+
+    if constexpr (chroma_mode(MODE)) {
+        // Waves entirely to the right of the chroma region only re-smooth what the previous pass left (all nine buffers'
+        // state in registers, the stale row of the next buffer in flight) and leave once every column from their first
+        // one on lies outside the dependency cone; their SIMD partners are waves of the region (wave i and i + 4).
+        if (wave * (kInner * PXL) >= a.region_w) {
+            const int x_wave = wave * (kInner * PXL);
+            float As[kBuffers][PXL];
+            const int v1 = (a.rows_in >= 1 && in_cone(1, a.cone_in)) ? io.v_a : kOutOfRange;
+#pragma unroll
+            for (int b = 0; b < kBuffers; ++b) io.finish(io.issue(b, 1, v1), As[b]);
+            for (int r = 1; r <= sweep; ++r) {
+                if (x_wave >= a.cone_w + 3 * (a.cone_nr - (r - 1) + 2) + a.cone_in) return;  // outside for good
+                const int vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+                PoolIO::RawPair s0 = io.issue(0, r + 1, vin), s1 = io.issue(1, r + 1, vin);
+                if (r > 1 && (r - 1) % K == 0) {
+                    __syncthreads();
+                    if (recv) {
+                        const unsigned* from = mb.at((r / K) & 1, wave, lane < GH ? 0 : 1, slot);
+#pragma unroll
+                        for (int b = 0; b < kBuffers; ++b)
+#pragma unroll
+                            for (int j = 0; j < PXL; ++j) As[b][j] = flt(from[b * PXL + j]);
+                    }
+                }
+                const int vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
+                const bool vout_any = __builtin_amdgcn_readfirstlane(__any(vout != kOutOfRange) ? 1 : 0) != 0;
+                stale_buffer_step<0>(As[0], s0, role, io, r, vout, vout_any);
+                s0 = io.issue(2, r + 1, vin);
+                stale_buffer_step<1>(As[1], s1, role, io, r, vout, vout_any);
+                s1 = io.issue(3, r + 1, vin);
+                stale_buffer_step<2>(As[2], s0, role, io, r, vout, vout_any);
+                s0 = io.issue(4, r + 1, vin);
+                stale_buffer_step<3>(As[3], s1, role, io, r, vout, vout_any);
+                s1 = io.issue(5, r + 1, vin);
+                stale_buffer_step<4>(As[4], s0, role, io, r, vout, vout_any);
+                s0 = io.issue(6, r + 1, vin);
+                stale_buffer_step<5>(As[5], s1, role, io, r, vout, vout_any);
+                s1 = io.issue(7, r + 1, vin);
+                stale_buffer_step<6>(As[6], s0, role, io, r, vout, vout_any);
+                s0 = io.issue(8, r + 1, vin);
+                stale_buffer_step<7>(As[7], s1, role, io, r, vout, vout_any);
+                stale_buffer_step<8>(As[8], s0, role, io, r, vout, vout_any);
+                if (r < sweep && r % K == 0) {
+                    if (pub_right || pub_left) {
+                        unsigned* to = pub_right ? mb.at(((r + 1) / K) & 1, wave + 1, 0, slot) : mb.at(((r + 1) / K) & 1, wave - 1, 1, slot);
+#pragma unroll
+                        for (int b = 0; b < kBuffers; ++b)
+#pragma unroll
+                            for (int j = 0; j < PXL; ++j) to[b * PXL + j] = bits(As[b][j]);
+                    }
+                }
+            }
+            return;
+        }
+    }
 
     Line L0, L1;
     Raw q0 = load_raw(src_line);
@@ -362,11 +549,20 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
 
     // A[1] = O[0] + P[1] = P[1] (pool row 0 is never written: zero, and 0 + x = x)
     float A[kRegBuffers][PXL];
+    const bool first_in = chroma_mode(MODE) && a.rows_in >= 1 && in_cone(1, a.cone_in);
     auto init_buf = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
         float t[PXL];
+        if constexpr (chroma_mode(MODE)) {
+            io.finish(io.issue(B, 1, first_in ? io.v_a : kOutOfRange), t);
+            if (nr > 0) {
 #pragma unroll
-        for (int j = 0; j < PXL; ++j) t[j] = nr > 0 ? (PADDED ? cost<B>(L0, L1, j) * role.inside : cost<B>(L0, L1, j)) : 0.0f;
+                for (int j = 0; j < PXL; ++j) t[j] = role.inside_b ? cost<B>(L0, L1, j) : t[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) t[j] = nr > 0 ? (PADDED ? cost<B>(L0, L1, j) * role.inside : cost<B>(L0, L1, j)) : 0.0f;
+        }
         if constexpr (B < kRegBuffers) {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) A[B][j] = t[j];
@@ -390,16 +586,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     Raw qn = nk > 2 ? load_raw(src_next) : q1;
     src_next += src_step;
 
-    // seam exchange: lanes 60, 61 feed the next wave's left ghosts, lanes 2, 3 the previous wave's right ghosts
-    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < NW - 1;
-    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
-    const bool recv = ghost && live;
-    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
-
     TurnTaking turns;
     turns.init(a.turn_shift);
-    auto step = [&](int r, Line& n, Line& nn, auto s1_tag) {
+    auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
         constexpr bool S1 = decltype(s1_tag)::value;
+        constexpr bool S3 = decltype(s3_tag)::value;
         turns.update();
         Raw qnext = qn;
         if constexpr (S1) {
@@ -429,10 +620,22 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
                 }
             }
         }
-        put(out_row, row_step<S1, PADDED>(A, parked, tid, n, nn, role, aaf));
-        out_row += dst_step;
+        RowCtx rc;
+        rc.r = r;
+        rc.vin = rc.vout = kOutOfRange;
+        rc.any_out = false;
+        if constexpr (chroma_mode(MODE)) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+        if constexpr (has_pools(MODE)) {
+            rc.vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
+            rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
+        }
+        const Out o = row_step<S1, S3, MODE>(A, parked, tid, n, nn, role, aaf, io, rc);
+        if constexpr (S3) {
+            put(out_row, o);
+            out_row += dst_step;
+        }
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c
-        if (r < nr && r % K == 0) {
+        if (r < sweep && r % K == 0) {
             const int wpar = ((r + 1) / K) & 1;
             if (pub_right || pub_left) {
                 unsigned* to = pub_right ? mb.at(wpar, wave + 1, 0, slot) : mb.at(wpar, wave - 1, 1, slot);
@@ -455,11 +658,12 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     using F = std::integral_constant<bool, false>;
 
     for (int r = 1; r < nr; ++r) {
-        step(r, L1, L0, T{});
+        step(r, L1, L0, T{}, T{});
         L1 = L0;
     }
-    if (nr >= 1) {
-        step(nr, L1, L0, F{});
+    if (nr >= 1) step(nr, L1, L0, F{}, T{});
+    if constexpr (chroma_mode(MODE)) {
+        for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
     }
 
     // dst row h-1 := K[nk-1] when the top field is kept, SangNom2.cpp:380-385
@@ -467,6 +671,27 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         const Raw q = load_raw(src_line + (nk - 1) * src_step);
         keep((2 * nk - 1) * a.dst_pitch, q);
     }
+}
+
+template <int MODE>
+static hipError_t launch_mode(hipStream_t st, const Args& a, float aaf, int nframes)
+{
+    const int g = v3c::group_of(a.nw);
+    const int lds = lds_bytes(a.nw, MODE) * g;
+    hipError_t e = hipSuccess;
+#define SN_LAUNCH(NW)                                                                                              \
+    case NW:                                                                                                       \
+        if (lds > 64 * 1024)                                                                                       \
+            e = hipFuncSetAttribute((const void*)k_fused_f32_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_fused_f32_v3<NW, MODE>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a, aaf); \
+        break;
+    switch (a.nw) {
+        SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef SN_LAUNCH
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
 }
 
 }  // namespace f32
@@ -477,7 +702,27 @@ bool fused_f32_plane_ok(int w)
     return v3c::strips_for(w / v3c::PXL) <= f32::kMaxWaves;
 }
 
-hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes, int sweep_w)
+int fused_f32_waves(int sweep_w) { return v3c::strips_for(sweep_w / v3c::PXL); }
+
+int64_t fused_f32_pool_bytes(int sweep_w, int rows) { return (int64_t)kBuffers * rows * fused_f32_waves(sweep_w) * 64 * 32; }
+
+// Slot of thread t = the O values of the 8 columns the lane owns (PoolIO::store); ghost lanes and lanes past the
+// sweep width own nothing.
+void fused_f32_pool_unpack(const uint32_t* raw, int sweep_w, int rows, float* out)
+{
+    using namespace v3c;
+    const int nl = sweep_w / PXL, nw = strips_for(nl), nt = nw * 64;
+    for (int64_t br = 0; br < (int64_t)kBuffers * rows; ++br)
+        for (int t = 0; t < nt; ++t) {
+            const int wave = t / 64, lane = t % 64;
+            const int gl = wave == 0 ? lane : kFirst + kInner * (wave - 1) + (lane - GH);
+            const bool ghost = wave == 0 ? (nw > 1 && lane >= 64 - GH) : (lane < GH || (lane >= 64 - GH && wave < nw - 1));
+            if (ghost || gl >= nl) continue;
+            std::memcpy(out + br * sweep_w + gl * PXL, raw + (br * nt + t) * 8, 8 * sizeof(float));
+        }
+}
+
+hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool)
 {
     v3c::Args a{};
     a.src = p.src;
@@ -486,7 +731,7 @@ hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.dst_frame_stride = p.dst_frame_stride;
     a.src_pitch = p.src_pitch;
     a.dst_pitch = p.dst_pitch;
-    a.w = sweep_w > 0 ? sweep_w : p.w;  // sweep_w: the pool stride a narrower plane is swept over (PADDED)
+    a.w = pool ? pool->sweep_w : p.w;  // sweep_w: the pool stride a narrower plane is swept over
     a.region_w = p.w;
     a.nk = p.h_out / 2;
     a.offset = p.offset;
@@ -499,28 +744,22 @@ hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
     const float aaf = (float)threshold;
-    const int g = v3c::group_of(a.nw);
-    const int lds = f32::lds_bytes(a.nw) * g;
-    hipError_t e = hipSuccess;
-#define SN_LAUNCH(NW)                                                                                              \
-    case NW:                                                                                                       \
-        if (sweep_w > 0) {                                                                                         \
-            if (lds > 64 * 1024)                                                                                   \
-                e = hipFuncSetAttribute((const void*)f32::k_fused_f32_v3<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            if (e == hipSuccess) hipLaunchKernelGGL((f32::k_fused_f32_v3<NW, true>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a, aaf); \
-        } else {                                                                                                   \
-            if (lds > 64 * 1024)                                                                                   \
-                e = hipFuncSetAttribute((const void*)f32::k_fused_f32_v3<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            if (e == hipSuccess) hipLaunchKernelGGL((f32::k_fused_f32_v3<NW, false>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a, aaf); \
-        }                                                                                                          \
-        break;
-    switch (a.nw) {
-        SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
-    default: return hipErrorInvalidValue;
-    }
-#undef SN_LAUNCH
-    if (e != hipSuccess) return e;
-    return hipGetLastError();
+    if (!pool) return f32::launch_mode<v3c::kPlain>(st, a, aaf, nframes);
+    if (pool->mode == v3c::kPadded) return f32::launch_mode<v3c::kPadded>(st, a, aaf, nframes);
+    a.pool_in = pool->pool_in;
+    a.pool_out = pool->pool_out;
+    a.pool_frame_stride = pool->frame_stride;
+    a.pool_rows = pool->pool_rows;
+    a.rows_in = pool->rows_in;
+    a.rows_out = pool->pool_out ? pool->rows_out : 0;
+    a.sweep_rows = pool->sweep_rows;
+    a.cone_w = pool->cone_w;
+    a.cone_nr = pool->cone_nr;
+    a.cone_in = pool->cone_in;
+    a.cone_out = pool->cone_out;
+    if (pool->mode == v3c::kLumaSpill) return f32::launch_mode<v3c::kLumaSpill>(st, a, aaf, nframes);
+    if (!pool->pool_out) return f32::launch_mode<v3c::kChromaLast>(st, a, aaf, nframes);
+    return f32::launch_mode<v3c::kChroma>(st, a, aaf, nframes);
 }
 
 }  // namespace sn

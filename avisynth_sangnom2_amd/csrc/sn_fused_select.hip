@@ -3,7 +3,7 @@
 // A configuration is eligible when every plane fits one workgroup (width a multiple of 32; up to 7680 columns for
 // 8-bit, 3840 for 16-bit and float samples) and either every processed plane is as large as the pool (no pass can
 // see another pass's leftovers: SURVEY.md 0.7) or the chroma planes are subsampled AND luma is processed first --
-// then the sweeps couple the passes through hand-off pools (8- and 16-bit); without a luma pass the chroma passes
+// then the sweeps couple the passes through hand-off pools; without a luma pass the chroma passes
 // would see the previous FRAME's leftovers, which only the pool path reproduces.
 #include <stdint.h>
 
@@ -36,7 +36,6 @@ bool fused_eligible(const sn_config& c)
 {
     if (!fused_plane_eligible(c.bytes_per_sample, c.width)) return false;
     if (chroma_subsampled_and_processed(c)) {
-        if (c.bytes_per_sample == 4) return false;  // no chroma coupling in the float sweep
         if (!(c.dh || c.luma)) return false;
         if ((c.width >> c.sub_w) % 8 != 0) return false;
     }

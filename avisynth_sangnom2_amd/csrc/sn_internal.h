@@ -82,9 +82,12 @@ hipError_t launch_fused_u8_v4(hipStream_t s, const PlaneArgs& p, double threshol
 #endif
 // sn_fused_u16_v3.hip: the same sweep for 9..16-bit samples (one pixel per register, up to 3840 wide).
 bool fused_u16_plane_ok(int w);
-// sn_fused_f32_v3.hip: the sweep for float samples (no chroma coupling: planes of equal size only).
+// sn_fused_f32_v3.hip: the sweep for float samples.
 bool fused_f32_plane_ok(int w);
-hipError_t launch_fused_f32_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes, int sweep_w = 0);
+int fused_f32_waves(int sweep_w);
+int64_t fused_f32_pool_bytes(int sweep_w, int rows);
+void fused_f32_pool_unpack(const uint32_t* raw, int sweep_w, int rows, float* out);
+hipError_t launch_fused_f32_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool);
 int fused_u16_waves(int sweep_w);
 int64_t fused_u16_pool_bytes(int sweep_w, int rows);
 void fused_u16_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint16_t* out);

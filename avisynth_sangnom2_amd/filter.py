@@ -50,6 +50,7 @@ _FORMATS = {
     "YUV422P8": dict(bytes=1, bits=8, planes=3, subw=1, subh=0),
     "YUV444P8": dict(bytes=1, bits=8, planes=3), "YUV444P16": dict(bytes=2, bits=16, planes=3),
     "YUV444PS": dict(bytes=4, bits=32, planes=3), "YUV420PS": dict(bytes=4, bits=32, planes=3, subw=1, subh=1),
+    "YUV422PS": dict(bytes=4, bits=32, planes=3, subw=1, subh=0),
 }
 
 

@@ -45,6 +45,7 @@ WORKLOADS = {
     "2160p-YUV420P16-dh": ("YUV420P16", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
     "2160p-Y32": ("Y32", 3840, 2160, dict(order=1, aa=48)),
+    "2160p-YUV420PS": ("YUV420PS", 3840, 2160, dict(order=1, aa=48, aac=48)),
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s

@@ -47,6 +47,7 @@ CASES = [
     ("YUV422P8", 64, 32, dict(aac=48)),
     ("YUV444P8", 64, 32, dict(aac=100, order=0)),
     ("YUV444PS", 64, 24, dict(dh=True, aac=48)),
+    ("YUV420PS", 128, 64, dict(aac=48)),
     ("YUV420P8", 64, 32, dict(dh=True, aac=48)),
     ("YUV420P16", 80, 32, dict(dh=True, luma=False, aac=5)),
 ]
@@ -233,7 +234,7 @@ FUSED_CASES += [
 
 
 FUSED_CASES += [
-    # float samples: sn_fused_f32_v3.hip (bit patterns must agree; no subsampled chroma)
+    # float samples: sn_fused_f32_v3.hip (bit patterns must agree)
     ("Y32", 64, 32, {}),
     ("Y32", 512, 20, dict(order=2)),
     ("Y32", 544, 24, dict(aa=100)),
@@ -249,6 +250,13 @@ FUSED_CASES += [
     ("YUV444PS", 576, 24, dict(aac=48)),
     ("YUV444PS", 64, 24, dict(dh=True, aac=48)),
     ("YUV420PS", 128, 32, dict(chroma=False)),
+    # float with subsampled chroma: the hand-off pools carry float bit patterns
+    ("YUV420PS", 128, 64, dict(aac=48)),
+    ("YUV420PS", 1024, 40, dict(aac=3, order=2)),
+    ("YUV420PS", 3840, 48, dict(aac=48)),
+    ("YUV422PS", 576, 28, dict(aac=48)),
+    ("YUV420PS", 96, 8, dict(aac=48)),
+    ("YUV420PS", 64, 32, dict(dh=True, aac=48)),
 ]
 
 
@@ -268,7 +276,7 @@ def test_fused_kernel_matches_oracle(hip_lib, fmt, w, h, kw, pattern):
 
 
 def test_fused_not_eligible_is_reported(hip_lib):
-    for fmt, w, h, kw in (("YUV420PS", 64, 32, dict(aac=48)), ("Y32", 3872, 16, {}), ("Y16", 3872, 16, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(luma=False, aac=1)),
+    for fmt, w, h, kw in (("YUV420PS", 64, 32, dict(luma=False, aac=48)), ("Y32", 3872, 16, {}), ("Y16", 3872, 16, {}), ("Y8", 100, 40, {}), ("YUV420P8", 64, 32, dict(luma=False, aac=1)),
                           ("Y8", 7712, 16, {})):
         with pytest.raises(SangNomError, match="not eligible"):
             SangNom2(clip_format(fmt, w, h), mode="fused", **kw)
@@ -339,8 +347,9 @@ def test_full_size_fused_equals_pool_and_oracle(hip_lib, name, fmt, w, h, kw, N)
 
 @pytest.mark.parametrize("fmt,w,h,kw", [("YUV420P16", 3840, 2160, dict(aa=48, aac=48)),
                                         ("YUV420P16", 3840, 1080, dict(aa=48, aac=48, dh=True)),
-                                        ("YUV444PS", 3840, 1080, dict(aa=48, aac=48, dh=True))],
-                         ids=["2160p YUV420P16", "2160p-out YUV420P16 dh", "2160p-out YUV444PS dh"])
+                                        ("YUV444PS", 3840, 1080, dict(aa=48, aac=48, dh=True)),
+                                        ("YUV420PS", 3840, 2160, dict(aa=48, aac=48))],
+                         ids=["2160p YUV420P16", "2160p-out YUV420P16 dh", "2160p-out YUV444PS dh", "2160p YUV420PS"])
 def test_full_size_16bit_and_float_match_oracle(hip_lib, fmt, w, h, kw):
     """BASELINE configuration 4 at full size, one frame each, against the oracle (float: bit patterns)."""
     clip = clip_format(fmt, w, h)
@@ -353,7 +362,8 @@ def test_full_size_16bit_and_float_match_oracle(hip_lib, fmt, w, h, kw):
 
 
 COUPLED = [("YUV420P8", 256, 64), ("YUV420P8", 1920, 1080), ("YUV420P8", 3840, 2160), ("YUV420P8", 7680, 360),
-           ("YUV420P10", 1920, 1080), ("YUV420P16", 640, 48), ("YUV420P16", 3840, 2160)]
+           ("YUV420P10", 1920, 1080), ("YUV420P16", 640, 48), ("YUV420P16", 3840, 2160),
+           ("YUV420PS", 640, 48), ("YUV420PS", 1920, 1080), ("YUV420PS", 3840, 2160)]
 
 
 @pytest.mark.parametrize("fmt,w,h", COUPLED, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in COUPLED])
@@ -381,8 +391,11 @@ def test_fused_420_hand_off_rows_match_the_shared_pool(hip_lib, fmt, w, h):
         # the rows below it matter (sn_fused_v3_common.h, Args::cone_*).  What lies outside is never written.
         w_c = w // 2
         for which, last, extra in ((0, rows - 1, 6), (1, min(nr_c + 1, bh - 1), 0)):
-            got = flt.read_coupled_rows(which)[:, 1:last + 1].astype(np.int64)
+            got = flt.read_coupled_rows(which)[:, 1:last + 1]
             exp = want[which][:, 1:last + 1, :w]
+            if clip.bytes == 4:  # float: bit patterns
+                got, exp = got.view(np.uint32), np.ascontiguousarray(exp, dtype=np.float32).view(np.uint32)
+            got, exp = got.astype(np.int64), exp.astype(np.int64)
             q = np.arange(1, last + 1)[:, None]
             x = np.arange(w)[None, :]
             cone = (x < w_c + 3 * (nr_c - q + 2) + extra) & ((x >= w_c) | (q > nr_c))
@@ -460,7 +473,7 @@ ISOLATED = [
     ("YUV420P8", 128, 64, dict(aac=30, order=0)),
     ("YUV420P16", 256, 48, dict(aac=48)),
     ("YUV422P8", 576, 28, dict(aac=48, order=2)),
-    ("YUV420PS", 128, 32, dict(aac=48)),                # float with subsampled chroma: fused only when isolated
+    ("YUV420PS", 128, 32, dict(aac=48)),
     ("YUV420P8", 200, 40, dict(aac=48)),                # luma 200, chroma 100 wide: every plane history-carrying
     ("YUV420P8", 320, 40, dict(aac=48, dh=True)),       # luma fused, chroma (160 wide) too
     ("YUV420P8", 192, 32, dict(aac=48, luma=False)),    # luma copied
