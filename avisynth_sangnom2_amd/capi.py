@@ -24,7 +24,7 @@ EXPORTS = (
     "sn_get_stream", "sn_get_info", "sn_debug_read_pool", "sn_debug_read_coupled_rows",
     "sn_host_slots", "sn_submit_host", "sn_collect_host", "sn_turn_device",
     "sn_aa_create", "sn_aa_process_host", "sn_aa_last_error", "sn_aa_destroy",
-    "sn_pin_host_buffer", "sn_unpin_host_buffer", "sn_submit_host_to",
+    "sn_pin_host_buffer", "sn_unpin_host_buffer", "sn_submit_host_to", "sn_debug_set_bands",
 )
 
 
@@ -41,7 +41,8 @@ class SnInfo(ctypes.Structure):
                 ("fused_eligible", ctypes.c_int32), ("history_free", ctypes.c_int32),
                 ("frames", ctypes.c_int64), ("fused_frames", ctypes.c_int64),
                 ("coupled_rows", ctypes.c_int32), ("reserved0", ctypes.c_int32),
-                ("threshold", ctypes.c_double * 3)]
+                ("threshold", ctypes.c_double * 3),
+                ("banded_frames", ctypes.c_int64), ("band_fallbacks", ctypes.c_int64)]
 
 
 def build(force: bool = False) -> str:
@@ -104,6 +105,7 @@ def load():
     L.sn_get_info.argtypes = [vp, ctypes.POINTER(SnInfo)]
     L.sn_debug_read_pool.argtypes = [vp, i32, vp, ctypes.c_size_t]
     L.sn_debug_read_coupled_rows.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    L.sn_debug_set_bands.argtypes = [vp, i32, i32]
     L.sn_pin_host_buffer.argtypes = [vp, ctypes.c_size_t]
     L.sn_unpin_host_buffer.argtypes = [vp]
     L.sn_submit_host_to.argtypes = [vp, p3v, p3i, p3v, p3i, i32, ctypes.POINTER(i32)]

@@ -93,6 +93,16 @@ struct Context {
     int64_t frames = 0, fused_frames = 0;
     std::string err;
 
+    // row-band sweeps of small launches (mode kBand, sn_fused_v3_common.h): per scratch slot the bands' state
+    // snapshots and the frame's flag; band_fallbacks is host memory the verification counts into
+    uint32_t* band_state = nullptr;
+    int32_t* band_flags = nullptr;
+    int64_t* band_fallbacks = nullptr;
+    int64_t band_words = 0;       // state words per slot
+    int64_t banded_frames = 0;
+    int band_force = 0;           // sn_debug_set_bands: bands per frame (0 = choose), < 0 = never
+    int band_warm = 0;            // rows of run-up (0 = the default of the sample type)
+
     int plane_w(int p) const { return p == 0 ? cfg.width : cfg.width >> cfg.sub_w; }
     int plane_h_in(int p) const { return p == 0 ? cfg.height : cfg.height >> cfg.sub_h; }
     int plane_h_out(int p) const { return p == 0 ? out_height : out_height >> cfg.sub_h; }
@@ -237,6 +247,9 @@ void sn_destroy(sn_context* h)
         if (c->plane_pool[p].base) (void)hipFree(c->plane_pool[p].base);
     for (int i = 0; i < 2; ++i)
         if (c->fpool[i]) (void)hipFree(c->fpool[i]);
+    if (c->band_state) (void)hipFree(c->band_state);
+    if (c->band_flags) (void)hipFree(c->band_flags);
+    if (c->band_fallbacks) (void)hipHostFree(c->band_fallbacks);
     delete c->copier;
     for (int p = 0; p < 3; ++p) {
         if (c->ring_pin_in[p]) (void)hipHostFree(c->ring_pin_in[p]);
@@ -479,6 +492,52 @@ static bool prefer_pool(const Context* c, int n, int slot0)
     return pool < 0.8 * fused;
 }
 
+// Row bands (mode kBand): a launch of a few frames -- a synchronous GetFrame, a short look-ahead -- cannot fill the
+// device with one workgroup per frame, so each frame is cut into bands of rows that start from a guessed state and are
+// verified afterwards (sn_fused_v3_common.h, sn_band.hip).  The run-up is what the guess needs to be forgotten on
+// ordinary content: 8-bit sums settle within 17-23 rows of noise, 16-bit within 30, float within 37.
+constexpr int kMaxBands = 128;
+constexpr int kMinBandRows = 8;
+
+static int band_warm_rows(const Context* c)
+{
+    if (c->band_warm > 0) return c->band_warm;
+    return c->cfg.bytes_per_sample == 1 ? 32 : c->cfg.bytes_per_sample == 2 ? 40 : 48;
+}
+
+// Bands per frame for a launch of n frames on slots slot0.., 0 = do not cut.
+static int band_count(const Context* c, int n, int slot0)
+{
+    if (c->band_force < 0 || c->cfg.mode != SN_MODE_AUTO || !c->use_fused || c->fused420 || c->isolated || !c->history_free) return 0;
+    if (slot0 + n > c->slots) return 0;  // the fallback needs the frames' pool slots
+    if (c->cfg.bytes_per_sample != 1) return 0;
+    if (c->band_force == 0)
+        if (const char* e = getenv("SN_PREFER_POOL"))  // 0: whole-plane sweeps always (see prefer_pool)
+            if (atoi(e) == 0) return 0;
+    int nr_min = 1 << 30;
+    for (int p = 0; p < c->nplanes(); ++p)
+        if (c->cfg.dh || c->process[p]) nr_min = c->plane_h_out(p) / 2 - 1 < nr_min ? c->plane_h_out(p) / 2 - 1 : nr_min;
+    if (nr_min == (1 << 30) || nr_min < 2 * kMinBandRows) return 0;
+    int nb = c->band_force > 0 ? c->band_force : 512 / n;  // about two workgroups per CU in all
+    if (nb > nr_min / kMinBandRows) nb = nr_min / kMinBandRows;
+    if (nb > kMaxBands) nb = kMaxBands;
+    if (c->band_force == 0 && nr_min / nb < band_warm_rows(c) / 4) nb = nr_min / (band_warm_rows(c) / 4);  // run-up <= 4 x own rows
+    return nb >= 2 ? nb : 0;
+}
+
+static int ensure_bands(Context* c)
+{
+    if (c->band_state) return SN_OK;
+    const int B = c->cfg.bytes_per_sample;
+    const int threads = 64 * (B == 4 ? sn::fused_f32_waves(c->cfg.width) : B == 2 ? sn::fused_u16_waves(c->cfg.width) : sn::fused_v3_waves(c->cfg.width));
+    c->band_words = sn::band_state_words(threads, kMaxBands);
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_state), (size_t)c->band_words * 4 * c->slots));
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_flags), sizeof(int32_t) * c->slots));
+    SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->band_fallbacks), sizeof(int64_t), hipHostMallocMapped));
+    *c->band_fallbacks = 0;
+    return SN_OK;
+}
+
 // Runs frames [f0, f0 + n) of a strided batch with one common field offset.
 // `st` is the stream to launch on and `slot0` the first scratch slot the frames may use (the batch entry points
 // pass the context's stream and slot 0, the host ring one frame on its slot's stream and scratch).
@@ -504,7 +563,10 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         a.enabled = (c->cfg.dh || c->process[p]) ? 1 : 0;
         fused[p] = a.enabled && (c->isolated ? c->plane_fused[p] : c->use_fused) && sn::fused_layout_ok(a);
     }
-    if (prefer_pool(c, n, slot0))
+    bool all_fused = true;
+    for (int p = 0; p < c->nplanes(); ++p) all_fused = all_fused && (fused[p] || !pa[p].enabled);
+    const int nbands = all_fused ? band_count(c, n, slot0) : 0;
+    if (nbands == 0 && prefer_pool(c, n, slot0))
         for (int p = 0; p < 3; ++p) fused[p] = false;
     auto frames_from = [](sn::PlaneArgs a, int i) {
         a.src += (int64_t)i * a.src_frame_stride;
@@ -592,6 +654,43 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
             }
         }
         c->fused_frames += n;
+        return SN_OK;
+    }
+
+    if (nbands) {
+        // the latency path: bands, their check, and the pool path for the frames that fail it (it exits at once otherwise)
+        int rc = ensure_bands(c);
+        if (rc == SN_OK) rc = ensure_pool(c);
+        if (rc != SN_OK) return rc;
+        for (int p = 0; p < c->nplanes(); ++p) {
+            sn::PlaneArgs a = pa[p];
+            if (!a.enabled) {
+                SN_HIP(c, sn::launch_assemble(st, a, c->cfg.bytes_per_sample, n));
+                continue;
+            }
+            const int nr = a.h_out / 2 - 1;
+            sn::FusedPool fp{};
+            fp.mode = 5;  // kBand
+            fp.nbands = nbands;
+            fp.band_rows = (nr + nbands - 1) / nbands;
+            fp.nbands = (nr + fp.band_rows - 1) / fp.band_rows;
+            fp.band_warm = band_warm_rows(c);
+            fp.band_state = c->band_state + (int64_t)slot0 * c->band_words;
+            fp.band_flags = c->band_flags + slot0;
+            const int B = c->cfg.bytes_per_sample;
+            int threads = 0;
+            if (B == 4) { SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, &fp)); threads = 64 * sn::fused_f32_waves(a.w); }
+            else if (B == 2) { SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp)); threads = 64 * sn::fused_u16_waves(a.w); }
+            else { SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp)); threads = 64 * sn::fused_v3_waves(a.w); }
+            SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks));
+            a.guard = fp.band_flags;
+            sn::PoolArgs pool = c->pool;
+            pool.guard = fp.band_flags;
+            SN_HIP(c, sn::launch_assemble(st, a, B, n));
+            SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(p), n, slot0));
+        }
+        c->fused_frames += n;
+        c->banded_frames += n;
         return SN_OK;
     }
 
@@ -1007,6 +1106,8 @@ int sn_get_info(sn_context* h, sn_info* info)
     info->fused_frames = c->fused_frames;
     info->coupled_rows = c->fused420 ? c->fpool_rows : 0;
     info->reserved0 = 0;
+    info->banded_frames = c->banded_frames;
+    info->band_fallbacks = c->band_fallbacks ? *c->band_fallbacks : 0;
     for (int p = 0; p < 3; ++p) info->threshold[p] = p < c->nplanes() ? c->threshold(p) : 0.0;
     return SN_OK;
 }
@@ -1022,6 +1123,16 @@ int sn_debug_read_pool(sn_context* h, int32_t slot, void* host_dst, size_t bytes
     SN_HIP(c, hipSetDevice(c->device));
     SN_HIP(c, hipStreamSynchronize(c->stream));
     SN_HIP(c, hipMemcpy(host_dst, c->pool.base + (int64_t)slot * c->pool.slot_bytes, need, hipMemcpyDeviceToHost));
+    return SN_OK;
+}
+
+int sn_debug_set_bands(sn_context* h, int32_t bands, int32_t warm_rows)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (bands > kMaxBands || warm_rows < 0) return sn::fail(c, SN_ERR_INVALID_ARG, "sn_debug_set_bands: at most %d bands, warm_rows >= 0", kMaxBands);
+    c->band_force = bands;
+    c->band_warm = warm_rows;
     return SN_OK;
 }
 

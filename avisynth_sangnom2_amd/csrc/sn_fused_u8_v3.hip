@@ -572,9 +572,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         v.y = first ? q.h[h].m0 : q.h[h].m1;
         return v;
     };
-    auto keep = [&](int row_off, const Raw& q) {  // GetFrame's field copy, SangNom2.cpp:365 / :376
-        __builtin_amdgcn_raw_buffer_store_b64(own(q, 0), rd, vstore[0], row_off, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(own(q, 1), rd, vstore[1], row_off, 0);
+    auto keep = [&](int row_off, const Raw& q, bool on = true) {  // GetFrame's field copy, SangNom2.cpp:365 / :376
+        __builtin_amdgcn_raw_buffer_store_b64(own(q, 0), rd, on ? vstore[0] : kOutOfRange, row_off, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(own(q, 1), rd, on ? vstore[1] : kOutOfRange, row_off, 0);
     };
     auto put = [&](int row_off, const Out& o) {
         u32x2 lo, hi;
@@ -626,15 +626,25 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
 
     const int nk = a.nk;
     const int nr = nk - 1;
-    const int sweep = chroma_mode(MODE) ? a.sweep_rows : nr;
+    // kBand: own rows ra .. rb, swept from row r0 on; everything else: the whole plane
+    int r0 = 1, ra = 1, rb = nr;
+    if constexpr (MODE == kBand) {
+        ra = 1 + (int)blockIdx.y * a.band_rows;
+        rb = ra + a.band_rows - 1 < nr ? ra + a.band_rows - 1 : nr;
+        r0 = ra - a.band_warm > 1 ? ra - a.band_warm : 1;
+        if (blockIdx.y == 0 && tid == 0) a.band_flags[f] = 0;
+    }
+    const bool top = ra == 1, bottom = rb == nr;  // the band with the first / the last row of the plane
+    const int sweep = chroma_mode(MODE) ? a.sweep_rows : rb;
     const unsigned thr_key = (unsigned)((a.thr + 1) << 4) * 0x00010001u;
 
+    // a band copies the kept lines ra .. rb (the top band line 0 as well)
     Line L0, L1;
-    Raw q0 = load_raw(src_line);
-    Raw q1 = nk > 1 ? load_raw(src_line + src_step) : q0;
-    keep(dst_line, q0);
-    if (a.offset == 1) keep(0, q0);  // the line that cannot be interpolated, SangNom2.cpp:386-391
-    if (nk > 1) keep(dst_line + dst_step, q1);
+    Raw q0 = load_raw(src_line + (r0 - 1) * src_step);
+    Raw q1 = nk > 1 ? load_raw(src_line + r0 * src_step) : q0;
+    keep(dst_line, q0, top);
+    if (a.offset == 1) keep(0, q0, top);  // the line that cannot be interpolated, SangNom2.cpp:386-391
+    if (nk > 1) keep(dst_line + r0 * dst_step, q1, r0 == ra);
     unpack(L0, q0, role);
     unpack(L1, q1, role);
     park_line(parked, tid, L0);  // c of row 1
@@ -680,10 +690,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     init_buf(std::integral_constant<int, 7>{});
     init_buf(std::integral_constant<int, 8>{});
 
-    int src_next = src_line + 2 * src_step;
-    int dst_keep = dst_line + 2 * dst_step;
-    int out_row = dst_line + a.dst_pitch;
-    Raw qn = nk > 2 ? load_raw(src_next) : q1;
+    int src_next = src_line + (r0 + 1) * src_step;
+    int dst_keep = dst_line + (r0 + 1) * dst_step;
+    int out_row = dst_line + a.dst_pitch + (r0 - 1) * dst_step;
+    Raw qn = r0 + 1 <= nr ? load_raw(src_next) : q1;
     src_next += src_step;
 
     // Seam exchange roles.  Lanes 60, 61 are the right seam lanes and lanes 2, 3 the left seam
@@ -707,7 +717,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
             unpack(nn, qn, role);  // waits for the line prefetched one row ago
-            keep(dst_keep, qn);
+            keep(dst_keep, qn, MODE != kBand || (r + 1 >= ra && r < rb));
             dst_keep += dst_step;
         }
         if constexpr (HAS_NEXT) {
@@ -715,7 +725,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             src_next += src_step;
         }
         const int par = (r / K) & 1;
-        if (r > 1 && (r - 1) % K == 0) {
+        if (r > r0 && (r - 1) % K == 0) {
             __syncthreads();
             if (recv_left || recv_right) {
                 const unsigned* from = reinterpret_cast<const unsigned*>(mb.at(par, wave, recv_left ? 0 : 1, slot));
@@ -750,10 +760,8 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             rc.any_out = __builtin_amdgcn_readfirstlane(__any((rc.vout != kOutOfRange) | (rc.vout_hi != kOutOfRange)) ? 1 : 0) != 0;
         }
         const Out o = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
-        if constexpr (S3) {  // stored at once: nothing is carried into the next row
-            put(out_row, o);
-            out_row += dst_step;
-        }
+        if constexpr (S3) put(out_row, o);  // stored at once: nothing is carried into the next row
+        out_row += dst_step;
         if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
         if (r < sweep) {
             if (r % K == 0) {
@@ -809,17 +817,41 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // pair, row nr does not (its next costs are zero or stale), rows beyond nr (kChroma only) have no
     // interpolated line either.  (Specialising the whole sweep on role.edge_wave -- two copies of the loop, no
     // branch per buffer step -- was tried: the register allocator then spills in both copies.)
-    for (int r = 1; r < nr; ++r) {
-        step(r, L1, L0, T{}, T{});
-        L1 = L0;
-    }
-    if (nr >= 1) step(nr, L1, L0, F{}, T{});
-    if constexpr (chroma_mode(MODE)) {
-        for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+    if constexpr (MODE == kBand) {
+        // the state the band holds on entering a row, as the next row's sweep sees it: real columns only
+        auto leave_state = [&](int which) {
+            const unsigned real_mask = (real[0] ? kLo : 0u) | (real[1] ? kHi : 0u);
+            uint32_t* to = a.band_state + ((int64_t)(f * a.nbands + (int)blockIdx.y) * 2 + which) * (kBuffers * PXL * NW * 64) + tid;
+#pragma unroll
+            for (int b = 0; b < kBuffers; ++b)
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * (NW * 64)] = A[b][j] & real_mask;
+        };
+        for (int r = r0; r < ra; ++r) {
+            step(r, L1, L0, T{}, F{});
+            L1 = L0;
+        }
+        leave_state(0);
+        const int re = bottom ? nr - 1 : rb;
+        for (int r = ra; r <= re; ++r) {
+            step(r, L1, L0, T{}, T{});
+            L1 = L0;
+        }
+        if (bottom) step(nr, L1, L0, F{}, T{});
+        else leave_state(1);
+    } else {
+        for (int r = 1; r < nr; ++r) {
+            step(r, L1, L0, T{}, T{});
+            L1 = L0;
+        }
+        if (nr >= 1) step(nr, L1, L0, F{}, T{});
+        if constexpr (chroma_mode(MODE)) {
+            for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+        }
     }
 
     // dst row h-1 := K[nk-1] when the top field is kept, SangNom2.cpp:380-385
-    if (a.offset == 0) {
+    if (a.offset == 0 && bottom) {
         const Raw q = load_raw(src_line + (nk - 1) * src_step);
         keep((2 * nk - 1) * a.dst_pitch, q);
     }
@@ -842,7 +874,8 @@ static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
     case NW:                                                                                                       \
         if (lds > 64 * 1024)                                                                                       \
             e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((v3::k_fused_u8_v3<NW, MODE>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a); \
+        if (e == hipSuccess)                                                                                       \
+            hipLaunchKernelGGL((v3::k_fused_u8_v3<NW, MODE>), dim3((nframes + g - 1) / g, MODE == v3::kBand ? a.nbands : 1), dim3(NW * g * 64), lds, st, a); \
         break;
     switch (a.nw) {
         SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
@@ -856,6 +889,7 @@ static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
 #ifdef SN_TU_PLAIN
 hipError_t launch_fused_u8_v3_plain(hipStream_t st, const v3c::Args& a, int nframes, int mode)
 {
+    if (mode == v3::kBand) return launch_mode<v3::kBand>(st, a, nframes);
     return mode == v3::kPadded ? launch_mode<v3::kPadded>(st, a, nframes) : launch_mode<v3::kPlain>(st, a, nframes);
 }
 #else
@@ -906,7 +940,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.dst_frame_stride = p.dst_frame_stride;
     a.src_pitch = p.src_pitch;
     a.dst_pitch = p.dst_pitch;
-    a.w = pool ? pool->sweep_w : p.w;
+    a.w = pool && pool->mode != v3::kBand ? pool->sweep_w : p.w;
     a.nk = p.h_out / 2;
     a.offset = p.offset;
     a.dh = p.dh;
@@ -920,6 +954,14 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
     a.nframes = nframes;
     if (!pool) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPlain);
+    if (pool->mode == v3::kBand) {
+        a.band_rows = pool->band_rows;
+        a.band_warm = pool->band_warm;
+        a.nbands = pool->nbands;
+        a.band_state = pool->band_state;
+        a.band_flags = pool->band_flags;
+        return launch_fused_u8_v3_plain(st, a, nframes, v3::kBand);
+    }
     a.pool_in = pool->pool_in;
     a.pool_out = pool->pool_out;
     a.pool_frame_stride = pool->frame_stride;

@@ -25,6 +25,7 @@ struct PlaneArgs {
     int32_t offset;            // first kept line (0 or 1)
     int32_t dh;
     int32_t enabled;           // processPlane[i] || dh
+    const int32_t* guard;      // pool-path kernels: when set, frame f is worked on only if guard[f] != 0 (sn_band.hip)
 };
 
 // Scratch pool geometry (src/SangNom2.cpp:287-288,305-310), in elements of T.
@@ -33,6 +34,7 @@ struct PoolArgs {
     int64_t slot_bytes;        // 9 * rows * stride_e * sizeof(T)
     int32_t stride_e;          // roundup(luma width, 32)
     int32_t bh;                // bufferHeight; a buffer has bh + 1 rows
+    const int32_t* guard;      // as PlaneArgs::guard
 };
 
 struct Context;
@@ -69,7 +71,16 @@ struct FusedPool {
     int sweep_rows;          // chroma: pool rows to sweep
     int cone_w, cone_nr;     // the chroma plane's width and interpolated lines (dependency cone of the hand-off, Args)
     int cone_in, cone_out;   // extra columns: what this pass loads / stores beyond the final pass's cone
+    // mode 5 (kBand): a plane on its own in bands of rows (sn_fused_v3_common.h); verified by launch_band_verify
+    int band_rows, band_warm, nbands;
+    uint32_t* band_state;    // nframes * band_state_words(threads, nbands) words
+    int32_t* band_flags;     // one per frame
 };
+// sn_band.hip: words of band state per frame for a sweep of `threads` threads; the check of a band launch -- flags[f] != 0
+// afterwards means frame f has to be redone by the pool path (its guarded launches look at the same flags);
+// *fallbacks (host-visible, may be null) counts such frames.
+inline int64_t band_state_words(int threads, int nbands) { return (int64_t)nbands * 2 * kBuffers * 8 * threads; }
+hipError_t launch_band_verify(hipStream_t s, const uint32_t* state, int threads, int nbands, int nframes, int32_t* flags, int64_t* fallbacks);
 int fused_v3_waves(int sweep_w);
 int64_t fused_v3_pool_bytes(int sweep_w, int rows);
 // host: scatter one scratch pool (thread-slot layout) into [9][rows][sweep_w] samples (test hook)

@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) k_assemble(PlaneArgs p, int row_bytes)
 {
     const int y = blockIdx.y;
     const int f = blockIdx.z;
+    if (p.guard && p.guard[f] == 0) return;
     const int sy = assemble_source_row(p, y);
     if (sy < 0) return;
     const uint8_t* s = p.src + (int64_t)f * p.src_frame_stride + (int64_t)sy * p.src_pitch;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(256) k_prepare(PlaneArgs p, PoolArgs pool, int
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int f = blockIdx.z;
+    if (p.guard && p.guard[f] == 0) return;
     if (x >= p.w) return;
     const uint8_t* plane = p.dst + (int64_t)f * p.dst_frame_stride;
     const T* cl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y) * p.dst_pitch);
@@ -155,6 +157,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
     W* line1 = line0 + se;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
+    if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     T* buf = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
     // the workgroup has ceil(se / NC) threads rounded up to whole waves; the idle lanes of the last wave compute on
@@ -215,6 +218,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_strided(PoolArgs pool
     W* line1 = line0 + se;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
+    if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     T* buf = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x;
@@ -279,6 +283,7 @@ k_finalize(PlaneArgs p, PoolArgs pool, int slot0, typename Px<T>::W thr)
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int f = blockIdx.z;
+    if (p.guard && p.guard[f] == 0) return;
     if (x >= p.w) return;
     uint8_t* plane = p.dst + (int64_t)f * p.dst_frame_stride;
     const T* cl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y) * p.dst_pitch);

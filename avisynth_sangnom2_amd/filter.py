@@ -137,6 +137,10 @@ class SangNom2:
         self._check(self._lib.sn_debug_read_pool(self._h, slot, out.ctypes.data, out.nbytes))
         return out
 
+    def set_bands(self, bands: int = 0, warm_rows: int = 0) -> None:
+        """Test hook: row bands of the small-launch path (sn_debug_set_bands)."""
+        self._check(self._lib.sn_debug_set_bands(self._h, bands, warm_rows))
+
     def read_coupled_rows(self, which: int) -> np.ndarray:
         """Rows the fused 4:2:0 sweep of plane `which` left for the next plane: [9, rows, width]."""
         rows = self.info().coupled_rows

@@ -105,6 +105,9 @@ typedef struct sn_info {
                                * plane (0: this configuration has no such hand-off)          */
     int32_t reserved0;
     double  threshold[3];     /* aaf[plane] after conversion to the sample type              */
+    int64_t banded_frames;    /* ... of fused_frames, swept in row bands (small launches)    */
+    int64_t band_fallbacks;   /* ... of which the check sent to the pool path (up to the     *
+                               * last synchronisation)                                       */
 } sn_info;
 
 /* Create_SangNom2's argument checks, same order, same message text (src/SangNom2.cpp:407-422).
@@ -204,6 +207,12 @@ int sn_debug_read_pool(sn_context* ctx, int32_t slot, void* host_dst, size_t byt
  * what rows 0..coupled_rows-1 of the reference's shared pool (src/SangNom2.cpp:322-329) hold at that
  * point, row 0 unused.  Synchronises the stream. */
 int sn_debug_read_coupled_rows(sn_context* ctx, int32_t which, void* host_dst, size_t bytes);
+
+/* Test hook for the row-band sweeps that serve small launches in SN_MODE_AUTO (a frame is cut into bands of
+ * rows that start `warm_rows` rows early from a guessed state and are verified; a frame that fails the check is
+ * redone by the pool path): bands > 0 forces that many bands per frame, 0 restores the automatic choice, < 0
+ * turns the bands off; warm_rows = 0 restores the default run-up.  A run-up of 1 makes nearly every frame fail. */
+int sn_debug_set_bands(sn_context* ctx, int32_t bands, int32_t warm_rows);
 
 int sn_abi_version(void);
 

@@ -14,7 +14,7 @@ int main(void)
                          (fn_t)sn_process_device_strided, (fn_t)sn_host_slots, (fn_t)sn_submit_host,
                          (fn_t)sn_collect_host, (fn_t)sn_turn_device, (fn_t)sn_synchronize,
                          (fn_t)sn_get_stream, (fn_t)sn_get_info, (fn_t)sn_debug_read_pool,
-                         (fn_t)sn_debug_read_coupled_rows, (fn_t)sn_aa_create, (fn_t)sn_aa_process_host,
+                         (fn_t)sn_debug_read_coupled_rows, (fn_t)sn_debug_set_bands, (fn_t)sn_aa_create, (fn_t)sn_aa_process_host,
                          (fn_t)sn_aa_last_error, (fn_t)sn_aa_destroy, (fn_t)sn_pin_host_buffer, (fn_t)sn_unpin_host_buffer,
                          (fn_t)sn_submit_host_to};
     sn_config c;

@@ -942,3 +942,59 @@ def test_pinned_host_frames_skip_the_staging_copies(hip_lib, fmt, w, h, kw):
             unpin_host_array(dbuf)
     with pytest.raises(SangNomError):
         unpin_host_array(sbuf)
+
+
+# ---- row bands: the small-launch path of SN_MODE_AUTO (sn_fused_v3_common.h kBand, sn_band.hip) -------------------
+
+BAND_CASES = [
+    # (pixel_type, width, height, kwargs, bands, warm_rows)
+    ("Y8", 256, 400, {}, 0, 0),                       # automatic cut
+    ("Y8", 1056, 300, dict(order=2), 4, 0),
+    ("Y8", 3840, 360, dict(aa=20), 7, 24),            # bands of unequal size
+    ("Y8", 64, 200, dict(order=0), 12, 0),            # two frames per workgroup (one wave per plane)
+    ("Y8", 960, 270, dict(dh=True), 5, 0),
+    ("YUV444P8", 320, 240, dict(aac=30), 6, 0),
+    ("YUV420P8", 256, 256, dict(chroma=False), 6, 0),  # chroma copied
+]
+
+
+@pytest.mark.parametrize("fmt,w,h,kw,bands,warm", BAND_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}-b{c[4]}" for c in BAND_CASES])
+@pytest.mark.parametrize("pattern", ["noise", "checker", "edges", "sine"])
+def test_row_bands_match_oracle(hip_lib, monkeypatch, fmt, w, h, kw, bands, warm, pattern):
+    """A frame cut into row bands equals the oracle whatever the content: where the run-up has not forgotten the
+    guessed state the check sends the frame to the pool path."""
+    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
+    clip = clip_format(fmt, w, h)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    with SangNom2(clip, **kw) as flt:
+        flt.set_bands(bands, warm)
+        for f, src in enumerate(make_frames(clip, pattern, 3, seed0=11)):
+            want = ora.process(src, parity=f & 1)
+            got = flt.get_frame(src, parity=f & 1)
+            for p in range(len(want)):
+                assert same(want[p], got[p]), f"{pattern} frame {f} plane {p}: " + describe_diff(want[p], got[p])
+        info = flt.info()
+        assert info.banded_frames == 3
+        if pattern == "noise" and warm == 0:
+            assert info.band_fallbacks == 0  # the default run-up is long enough for noise
+
+
+@pytest.mark.parametrize("fmt,w,h", [("Y8", 512, 300), ("Y8", 3840, 2160)])
+def test_row_bands_that_fail_the_check_are_redone(hip_lib, monkeypatch, fmt, w, h):
+    """A run-up of one row leaves nearly every band with a wrong state: the check must notice and the pool path must
+    repair every such frame."""
+    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
+    clip = clip_format(fmt, w, h)
+    ora = Oracle(oracle_cfg(clip))
+    with SangNom2(clip) as flt:
+        flt.set_bands(16, 1)
+        for f, src in enumerate(make_frames(clip, "noise", 2, seed0=3)):
+            want = ora.process(src)
+            got = flt.get_frame(src)
+            assert same(want[0], got[0]), f"frame {f}: " + describe_diff(want[0], got[0])
+        info = flt.info()
+        assert info.banded_frames == 2 and info.band_fallbacks == 2
+        flt.set_bands(-1, 0)  # bands off: the same frames through the pool path / plain sweep
+        got = flt.get_frame(src)
+        assert same(want[0], got[0])
+        assert flt.info().banded_frames == 2
