@@ -93,15 +93,21 @@ struct Context {
     int64_t frames = 0, fused_frames = 0;
     std::string err;
 
-    // row-band sweeps of small launches (mode kBand, sn_fused_v3_common.h): per scratch slot the bands' state
-    // snapshots and the frame's flag; band_fallbacks is host memory the verification counts into
+    // row-band sweeps of small launches (sn_fused_v3_common.h): per scratch slot the bands' state
+    // snapshots and the frame's flag; the verification counts failed frames in band_fallbacks_dev, copied to the
+    // pinned band_fallbacks behind every banded launch
     uint32_t* band_state = nullptr;
     int32_t* band_flags = nullptr;
     int64_t* band_fallbacks = nullptr;
+    int64_t* band_fallbacks_dev = nullptr;
     int64_t band_words = 0;       // state words per slot
     int64_t banded_frames = 0;
     int band_force = 0;           // sn_debug_set_bands: bands per frame (0 = choose), < 0 = never
     int band_warm = 0;            // rows of run-up (0 = the default of the sample type)
+    // content on which the check keeps failing (flat or periodic material) pays for the bands AND the pool path: after
+    // a failure the next launches go straight to the pool path, twice as many after every further one
+    int64_t band_fallbacks_seen = 0;
+    int band_pause = 0, band_pause_next = 0, band_good = 0;
 
     int plane_w(int p) const { return p == 0 ? cfg.width : cfg.width >> cfg.sub_w; }
     int plane_h_in(int p) const { return p == 0 ? cfg.height : cfg.height >> cfg.sub_h; }
@@ -250,6 +256,7 @@ void sn_destroy(sn_context* h)
     if (c->band_state) (void)hipFree(c->band_state);
     if (c->band_flags) (void)hipFree(c->band_flags);
     if (c->band_fallbacks) (void)hipHostFree(c->band_fallbacks);
+    if (c->band_fallbacks_dev) (void)hipFree(c->band_fallbacks_dev);
     delete c->copier;
     for (int p = 0; p < 3; ++p) {
         if (c->ring_pin_in[p]) (void)hipHostFree(c->ring_pin_in[p]);
@@ -492,7 +499,7 @@ static bool prefer_pool(const Context* c, int n, int slot0)
     return pool < 0.8 * fused;
 }
 
-// Row bands (mode kBand): a launch of a few frames -- a synchronous GetFrame, a short look-ahead -- cannot fill the
+// Row bands: a launch of a few frames -- a synchronous GetFrame, a short look-ahead -- cannot fill the
 // device with one workgroup per frame, so each frame is cut into bands of rows that start from a guessed state and are
 // verified afterwards (sn_fused_v3_common.h, sn_band.hip).  The run-up is what the guess needs to be forgotten on
 // ordinary content: 8-bit sums settle within 17-23 rows of noise, 16-bit within 30, float within 37.
@@ -506,11 +513,10 @@ static int band_warm_rows(const Context* c)
 }
 
 // Bands per frame for a launch of n frames on slots slot0.., 0 = do not cut.
-static int band_count(const Context* c, int n, int slot0)
+static int band_count(Context* c, int n, int slot0)
 {
     if (c->band_force < 0 || c->cfg.mode != SN_MODE_AUTO || !c->use_fused || c->fused420 || c->isolated || !c->history_free) return 0;
     if (slot0 + n > c->slots) return 0;  // the fallback needs the frames' pool slots
-    if (c->cfg.bytes_per_sample != 1) return 0;
     if (c->band_force == 0)
         if (const char* e = getenv("SN_PREFER_POOL"))  // 0: whole-plane sweeps always (see prefer_pool)
             if (atoi(e) == 0) return 0;
@@ -518,6 +524,21 @@ static int band_count(const Context* c, int n, int slot0)
     for (int p = 0; p < c->nplanes(); ++p)
         if (c->cfg.dh || c->process[p]) nr_min = c->plane_h_out(p) / 2 - 1 < nr_min ? c->plane_h_out(p) / 2 - 1 : nr_min;
     if (nr_min == (1 << 30) || nr_min < 2 * kMinBandRows) return 0;
+    if (c->band_force == 0 && c->band_fallbacks) {
+        const int64_t seen = *c->band_fallbacks;  // as of the last banded launch that has finished
+        if (seen != c->band_fallbacks_seen) {
+            c->band_fallbacks_seen = seen;
+            c->band_pause_next = c->band_pause_next < 8 ? 8 : c->band_pause_next < 1024 ? 2 * c->band_pause_next : 1024;
+            c->band_pause = c->band_pause_next;
+            c->band_good = 0;
+        } else if (c->band_pause == 0 && ++c->band_good >= 64) {
+            c->band_pause_next = 0;
+        }
+        if (c->band_pause > 0) {
+            --c->band_pause;
+            return 0;
+        }
+    }
     int nb = c->band_force > 0 ? c->band_force : 512 / n;  // about two workgroups per CU in all
     if (nb > nr_min / kMinBandRows) nb = nr_min / kMinBandRows;
     if (nb > kMaxBands) nb = kMaxBands;
@@ -525,15 +546,39 @@ static int band_count(const Context* c, int n, int slot0)
     return nb >= 2 ? nb : 0;
 }
 
+// The band fields of one sweep over pool rows 1 .. last, at most `want` bands.
+static void set_bands(const Context* c, sn::FusedPool& fp, int want, int last, int slot0, bool first)
+{
+    int nb = want < last / kMinBandRows ? want : last / kMinBandRows;
+    if (nb < 1) nb = 1;
+    fp.band_rows = (last + nb - 1) / nb;
+    fp.nbands = (last + fp.band_rows - 1) / fp.band_rows;
+    if (fp.nbands < 2) {  // a launcher takes one band as "not cut"; two bands of which the second is empty cannot happen
+        fp.band_rows = (last + 1) / 2;
+        fp.nbands = 2;
+    }
+    fp.band_warm = band_warm_rows(c);
+    fp.band_state = c->band_state + (int64_t)slot0 * c->band_words;
+    fp.band_flags = c->band_flags + slot0;
+    fp.band_reset = first ? 1 : 0;
+}
+
+static int band_threads(const Context* c)
+{
+    const int B = c->cfg.bytes_per_sample;
+    return 64 * (B == 4 ? sn::fused_f32_waves(c->cfg.width) : B == 2 ? sn::fused_u16_waves(c->cfg.width) : sn::fused_v3_waves(c->cfg.width));
+}
+
 static int ensure_bands(Context* c)
 {
     if (c->band_state) return SN_OK;
-    const int B = c->cfg.bytes_per_sample;
-    const int threads = 64 * (B == 4 ? sn::fused_f32_waves(c->cfg.width) : B == 2 ? sn::fused_u16_waves(c->cfg.width) : sn::fused_v3_waves(c->cfg.width));
-    c->band_words = sn::band_state_words(threads, kMaxBands);
+    c->band_words = sn::band_state_words(band_threads(c), kMaxBands);
     SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_state), (size_t)c->band_words * 4 * c->slots));
     SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_flags), sizeof(int32_t) * c->slots));
-    SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->band_fallbacks), sizeof(int64_t), hipHostMallocMapped));
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_fallbacks_dev), sizeof(int64_t)));
+    SN_HIP(c, hipMemsetAsync(c->band_fallbacks_dev, 0, sizeof(int64_t), c->stream));
+    SN_HIP(c, hipStreamSynchronize(c->stream));
+    SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->band_fallbacks), sizeof(int64_t), hipHostMallocDefault));
     *c->band_fallbacks = 0;
     return SN_OK;
 }
@@ -657,7 +702,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         return SN_OK;
     }
 
-    if (nbands) {
+    if (nbands && !c->fused420) {
         // the latency path: bands, their check, and the pool path for the frames that fail it (it exits at once otherwise)
         int rc = ensure_bands(c);
         if (rc == SN_OK) rc = ensure_pool(c);
@@ -668,27 +713,22 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
                 SN_HIP(c, sn::launch_assemble(st, a, c->cfg.bytes_per_sample, n));
                 continue;
             }
-            const int nr = a.h_out / 2 - 1;
             sn::FusedPool fp{};
-            fp.mode = 5;  // kBand
-            fp.nbands = nbands;
-            fp.band_rows = (nr + nbands - 1) / nbands;
-            fp.nbands = (nr + fp.band_rows - 1) / fp.band_rows;
-            fp.band_warm = band_warm_rows(c);
-            fp.band_state = c->band_state + (int64_t)slot0 * c->band_words;
-            fp.band_flags = c->band_flags + slot0;
+            fp.mode = 0;  // kPlain, in bands
+            set_bands(c, fp, nbands, a.h_out / 2 - 1, slot0, true);
             const int B = c->cfg.bytes_per_sample;
-            int threads = 0;
-            if (B == 4) { SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, &fp)); threads = 64 * sn::fused_f32_waves(a.w); }
-            else if (B == 2) { SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp)); threads = 64 * sn::fused_u16_waves(a.w); }
-            else { SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp)); threads = 64 * sn::fused_v3_waves(a.w); }
-            SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks));
+            if (B == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, &fp));
+            else if (B == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
+            else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp));
+            const int threads = 64 * (B == 4 ? sn::fused_f32_waves(a.w) : B == 2 ? sn::fused_u16_waves(a.w) : sn::fused_v3_waves(a.w));
+            SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks_dev));
             a.guard = fp.band_flags;
             sn::PoolArgs pool = c->pool;
             pool.guard = fp.band_flags;
             SN_HIP(c, sn::launch_assemble(st, a, B, n));
             SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(p), n, slot0));
         }
+        SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         c->fused_frames += n;
         c->banded_frames += n;
         return SN_OK;

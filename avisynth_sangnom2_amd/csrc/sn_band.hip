@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_band_verify(const uint32_t* state, int 
         diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
     }
     if (__syncthreads_or(diff != 0) && threadIdx.x == 0) {
-        if (atomicExch(&flags[f], 1) == 0 && fallbacks) atomicAdd_system(reinterpret_cast<unsigned long long*>(fallbacks), 1ull);
+        if (atomicExch(&flags[f], 1) == 0 && fallbacks) atomicAdd(reinterpret_cast<unsigned long long*>(fallbacks), 1ull);
     }
 }
 

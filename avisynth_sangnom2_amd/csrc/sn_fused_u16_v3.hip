@@ -390,7 +390,7 @@ __host__ __device__ constexpr int lds_bytes(int nw, int mode)
     return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
 }
 
-template <int NW, int MODE>
+template <int NW, int MODE, bool BAND>
 __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -456,11 +456,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         q.b = __builtin_amdgcn_raw_buffer_load_b128(rs, vload, row_off + 16, 0);
         return q;
     };
-    auto keep = [&](int row_off, const Raw& q) {  // GetFrame's field copy: the lane's own 8 pixels
+    auto keep = [&](int row_off, const Raw& q, bool on = true) {  // GetFrame's field copy: the lane's own 8 pixels
         u32x4 v;
         if (role.first) v = q.a;                       // loaded from column 0: own pixels come first
         else { v.x = q.a.z; v.y = q.a.w; v.z = q.b.x; v.w = q.b.y; }
-        store_b128(v, rd, vstore, row_off);
+        store_b128(v, rd, on ? vstore : kOutOfRange, row_off);
     };
     auto put = [&](int row_off, const Out& o) { store_b128(o.v, rd, vstore, row_off); };
 
@@ -497,7 +497,17 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
 
     const int nk = a.nk;
     const int nr = nk - 1;
-    const int sweep = chroma_mode(MODE) ? a.sweep_rows : nr;
+    // BAND (planes on their own only, sn_fused_v3_common.h): own rows ra .. rb, swept from row r0 on
+    static_assert(!(BAND && has_pools(MODE)), "the pool-coupled sweeps are not cut");
+    int r0 = 1, ra = 1, rb = nr;
+    if constexpr (BAND) {
+        ra = 1 + (int)blockIdx.y * a.band_rows;
+        rb = ra + a.band_rows - 1 < nr ? ra + a.band_rows - 1 : nr;
+        r0 = ra - a.band_warm > 1 ? ra - a.band_warm : 1;
+        if (a.band_reset && blockIdx.y == 0 && tid == 0) a.band_flags[f] = 0;
+    }
+    const bool top = ra == 1;
+    const int sweep = chroma_mode(MODE) ? a.sweep_rows : rb;
     const unsigned thr_key = (unsigned)(a.thr + 1) << 4;
 
     if constexpr (chroma_mode(MODE)) {
@@ -562,12 +572,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         }
     }
 
+    // a band copies the kept lines ra .. rb (the top band line 0 as well)
     Line L0, L1;
-    Raw q0 = load_raw(src_line);
-    Raw q1 = nk > 1 ? load_raw(src_line + src_step) : q0;
-    keep(dst_line, q0);
-    if (a.offset == 1) keep(0, q0);  // the line that cannot be interpolated, SangNom2.cpp:386-391
-    if (nk > 1) keep(dst_line + dst_step, q1);
+    Raw q0 = load_raw(src_line + (r0 - 1) * src_step);
+    Raw q1 = nk > 1 ? load_raw(src_line + r0 * src_step) : q0;
+    keep(dst_line, q0, top);
+    if (a.offset == 1) keep(0, q0, top);  // the line that cannot be interpolated, SangNom2.cpp:386-391
+    if (nk > 1) keep(dst_line + r0 * dst_step, q1, r0 == ra);
     unpack(L0, q0, role);
     unpack(L1, q1, role);
     parked.park(tid, L0);
@@ -586,10 +597,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
             }
         } else if constexpr (MODE == kPadded) {
 #pragma unroll
-            for (int j = 0; j < PXL; ++j) Ab[j] = (nr > 0 && role.inside) ? cost<B>(L0, L1, j) : 0u;
+            for (int j = 0; j < PXL; ++j) Ab[j] = (r0 <= nr && role.inside) ? cost<B>(L0, L1, j) : 0u;
         } else {
 #pragma unroll
-            for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? cost<B>(L0, L1, j) : 0u;
+            for (int j = 0; j < PXL; ++j) Ab[j] = r0 <= nr ? cost<B>(L0, L1, j) : 0u;
         }
     };
     auto init_buf = [&](auto buf) {
@@ -612,10 +623,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     init_buf(std::integral_constant<int, 7>{});
     init_buf(std::integral_constant<int, 8>{});
 
-    int src_next = src_line + 2 * src_step;
-    int dst_keep = dst_line + 2 * dst_step;
-    int out_row = dst_line + a.dst_pitch;
-    Raw qn = nk > 2 ? load_raw(src_next) : q1;
+    int src_next = src_line + (r0 + 1) * src_step;
+    int dst_keep = dst_line + (r0 + 1) * dst_step;
+    int out_row = dst_line + a.dst_pitch + (r0 - 1) * dst_step;  // where the pending row goes
+    Raw qn = r0 + 1 <= nr ? load_raw(src_next) : q1;
     src_next += src_step;
 
     Out pending{};
@@ -628,11 +639,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         Raw qnext = qn;
         if constexpr (S1) {
             unpack(nn, qn, role);  // waits for the line prefetched one row ago
-            keep(dst_keep, qn);
+            keep(dst_keep, qn, !BAND || (r + 1 >= ra && r < rb));
             dst_keep += dst_step;
         }
-        if (r > 1 && r <= nr) {
-            put(out_row, pending);  // stored here, after the prefetch wait (vmcnt counts in order)
+        if (r > r0 && r <= nr) {
+            if (!BAND || r > ra) put(out_row, pending);  // stored here, after the prefetch wait (vmcnt counts in order)
             out_row += dst_step;
         }
         if constexpr (S1) {
@@ -640,7 +651,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
             src_next += src_step;
         }
         const int par = (r / K) & 1;
-        if (r > 1 && (r - 1) % K == 0) {
+        if (r > r0 && (r - 1) % K == 0) {
             __syncthreads();
             if (recv) {
                 const unsigned* from = mb.at(par, wave, lane < GH ? 0 : 1, slot);
@@ -690,26 +701,58 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     using T = std::integral_constant<bool, true>;
     using F = std::integral_constant<bool, false>;
 
-    for (int r = 1; r < nr; ++r) {
-        step(r, L1, L0, T{}, T{});
-        L1 = L0;
-    }
-    if (nr >= 1) {
-        step(nr, L1, L0, F{}, T{});
+    if constexpr (BAND) {
+        // the state the band holds on entering a row: real columns only
+        auto leave_state = [&](int which) {
+            uint32_t* to = a.band_state + ((int64_t)(f * a.nbands + (int)blockIdx.y) * 2 + which) * (kBuffers * PXL * NT) + tid;
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * NT] = real ? A[b][j] : 0u;
+#pragma unroll
+            for (int b = RB; b < kBuffers; ++b) {
+                unsigned t[PXL];
+                parked.load_A(tid, b, t);
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * NT] = real ? t[j] : 0u;
+            }
+        };
+        int r = r0;
+        for (; r < ra; ++r) {  // the run-up: nothing interpolated
+            step(r, L1, L0, T{}, F{});
+            L1 = L0;
+        }
+        leave_state(0);
+        const int own_next = rb < nr ? rb + 1 : nr;
+        for (; r < own_next; ++r) {
+            step(r, L1, L0, T{}, T{});
+            L1 = L0;
+        }
+        if (rb == nr) step(nr, L1, L0, F{}, T{});
+        else leave_state(1);
         put(out_row, pending);
-    }
-    if constexpr (chroma_mode(MODE)) {
-        for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+    } else {
+        for (int r = 1; r < nr; ++r) {
+            step(r, L1, L0, T{}, T{});
+            L1 = L0;
+        }
+        if (nr >= 1) {
+            step(nr, L1, L0, F{}, T{});
+            put(out_row, pending);
+        }
+        if constexpr (chroma_mode(MODE)) {
+            for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+        }
     }
 
     // dst row h-1 := K[nk-1] when the top field is kept, SangNom2.cpp:380-385
-    if (a.offset == 0) {
+    if (a.offset == 0 && rb == nr) {
         const Raw q = load_raw(src_line + (nk - 1) * src_step);
         keep((2 * nk - 1) * a.dst_pitch, q);
     }
 }
 
-template <int MODE>
+template <int MODE, bool BAND = false>
 static hipError_t launch_mode(hipStream_t st, const Args& a, int nframes)
 {
     const int g = v3c::group_of(a.nw);
@@ -718,8 +761,9 @@ static hipError_t launch_mode(hipStream_t st, const Args& a, int nframes)
 #define SN_LAUNCH(NW)                                                                                              \
     case NW:                                                                                                       \
         if (lds > 64 * 1024)                                                                                       \
-            e = hipFuncSetAttribute((const void*)k_fused_u16_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((k_fused_u16_v3<NW, MODE>), dim3((nframes + g - 1) / g), dim3(NW * g * 64), lds, st, a); \
+            e = hipFuncSetAttribute((const void*)k_fused_u16_v3<NW, MODE, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e == hipSuccess)                                                                                       \
+            hipLaunchKernelGGL((k_fused_u16_v3<NW, MODE, BAND>), dim3((nframes + g - 1) / g, BAND ? a.nbands : 1), dim3(NW * g * 64), lds, st, a); \
         break;
     switch (a.nw) {
         SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
@@ -769,7 +813,7 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.dst_frame_stride = p.dst_frame_stride;
     a.src_pitch = p.src_pitch;
     a.dst_pitch = p.dst_pitch;
-    a.w = pool ? pool->sweep_w : p.w;
+    a.w = pool && pool->mode != v3c::kPlain ? pool->sweep_w : p.w;
     a.nk = p.h_out / 2;
     a.offset = p.offset;
     a.dh = p.dh;
@@ -782,6 +826,17 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
     if (!pool) return w16::launch_mode<v3c::kPlain>(st, a, nframes);
+    if (pool->nbands > 1) {
+        a.band_rows = pool->band_rows;
+        a.band_warm = pool->band_warm;
+        a.nbands = pool->nbands;
+        a.band_state = pool->band_state;
+        a.band_flags = pool->band_flags;
+        a.band_reset = pool->band_reset;
+        if (pool->mode == v3c::kPlain) return w16::launch_mode<v3c::kPlain, true>(st, a, nframes);
+        return hipErrorInvalidValue;  // only planes on their own are cut
+    }
+    if (pool->mode == v3c::kPlain) return w16::launch_mode<v3c::kPlain>(st, a, nframes);
     a.pool_in = pool->pool_in;
     a.pool_out = pool->pool_out;
     a.pool_frame_stride = pool->frame_stride;

@@ -484,7 +484,7 @@ __host__ __device__ constexpr int lds_bytes(int nw, int mode)
     return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + mailbox_copies(mode) * nw * 2 * GH * kBuffers * PXL * 4;
 }
 
-template <int NW, int MODE>
+template <int NW, int MODE, bool BAND>
 __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -626,16 +626,18 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
 
     const int nk = a.nk;
     const int nr = nk - 1;
-    // kBand: own rows ra .. rb, swept from row r0 on; everything else: the whole plane
-    int r0 = 1, ra = 1, rb = nr;
-    if constexpr (MODE == kBand) {
+    const int last = chroma_mode(MODE) ? a.sweep_rows : nr;  // pool rows 1 .. last are swept
+    // BAND: own rows ra .. rb, swept from row r0 on; otherwise the whole plane
+    int r0 = 1, ra = 1, rb = last;
+    if constexpr (BAND) {
         ra = 1 + (int)blockIdx.y * a.band_rows;
-        rb = ra + a.band_rows - 1 < nr ? ra + a.band_rows - 1 : nr;
+        rb = ra + a.band_rows - 1 < last ? ra + a.band_rows - 1 : last;
         r0 = ra - a.band_warm > 1 ? ra - a.band_warm : 1;
-        if (blockIdx.y == 0 && tid == 0) a.band_flags[f] = 0;
+        if (a.band_reset && blockIdx.y == 0 && tid == 0) a.band_flags[f] = 0;
     }
-    const bool top = ra == 1, bottom = rb == nr;  // the band with the first / the last row of the plane
-    const int sweep = chroma_mode(MODE) ? a.sweep_rows : rb;
+    const bool top = ra == 1;                    // the band with the first row of the plane
+    const bool bottom = rb >= nr;                // ... with its last interpolated line
+    const int sweep = rb;
     const unsigned thr_key = (unsigned)((a.thr + 1) << 4) * 0x00010001u;
 
     // a band copies the kept lines ra .. rb (the top band line 0 as well)
@@ -644,7 +646,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     Raw q1 = nk > 1 ? load_raw(src_line + r0 * src_step) : q0;
     keep(dst_line, q0, top);
     if (a.offset == 1) keep(0, q0, top);  // the line that cannot be interpolated, SangNom2.cpp:386-391
-    if (nk > 1) keep(dst_line + r0 * dst_step, q1, r0 == ra);
+    if (nk > 1) keep(dst_line + r0 * dst_step, q1, r0 == ra && r0 <= nr);
     unpack(L0, q0, role);
     unpack(L1, q1, role);
     park_line(parked, tid, L0);  // c of row 1
@@ -652,22 +654,22 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // A[1] = O[0] + P[1] = P[1] (pool row 0 is never written: zero); P[1] = stage-1 costs of the first
     // line pair, and outside the chroma region (kChroma) what the previous pass left in row 1
     unsigned A[kRegBuffers][PXL];
-    const bool first_lo = chroma_mode(MODE) && a.rows_in >= 1 && in_cone(1, a.cone_in, 0);
-    const bool first_hi = chroma_mode(MODE) && a.rows_in >= 1 && in_cone(1, a.cone_in, 1);
+    const bool first_lo = chroma_mode(MODE) && a.rows_in >= r0 && in_cone(r0, a.cone_in, 0);
+    const bool first_hi = chroma_mode(MODE) && a.rows_in >= r0 && in_cone(r0, a.cone_in, 1);
     auto init_A = [&](auto buf, unsigned (&Ab)[PXL]) {
         constexpr int B = decltype(buf)::value;
         if constexpr (chroma_mode(MODE)) {
-            io.load(B, 1, first_lo ? io.v_lo : kOutOfRange, first_hi ? io.v_hi : kOutOfRange, Ab);
-            if (nr > 0) {
+            io.load(B, r0, first_lo ? io.v_lo : kOutOfRange, first_hi ? io.v_hi : kOutOfRange, Ab);
+            if (r0 <= nr) {
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) Ab[j] = bfi(role.inside_mask, cost<B>(L0, L1, j), Ab[j]);
             }
         } else if constexpr (MODE == kPadded) {
 #pragma unroll
-            for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? (cost<B>(L0, L1, j) & role.inside_mask) : 0u;
+            for (int j = 0; j < PXL; ++j) Ab[j] = r0 <= nr ? (cost<B>(L0, L1, j) & role.inside_mask) : 0u;
         } else {
 #pragma unroll
-            for (int j = 0; j < PXL; ++j) Ab[j] = nr > 0 ? cost<B>(L0, L1, j) : 0u;
+            for (int j = 0; j < PXL; ++j) Ab[j] = r0 <= nr ? cost<B>(L0, L1, j) : 0u;
         }
     };
     auto init_buf = [&](auto buf) {
@@ -717,7 +719,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
             unpack(nn, qn, role);  // waits for the line prefetched one row ago
-            keep(dst_keep, qn, MODE != kBand || (r + 1 >= ra && r < rb));
+            keep(dst_keep, qn, !BAND || (r + 1 >= ra && r < rb));
             dst_keep += dst_step;
         }
         if constexpr (HAS_NEXT) {
@@ -754,7 +756,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             rc.vin_hi = (row_in && in_cone(r + 1, a.cone_in, 1)) ? io.v_hi : kOutOfRange;
         }
         if constexpr (has_pools(MODE)) {
-            const bool row_out = r <= a.rows_out;
+            const bool row_out = r <= a.rows_out && (!BAND || r >= ra);
             rc.vout = (row_out && in_cone(r, a.cone_out, 0)) ? io.v_out_lo : kOutOfRange;
             rc.vout_hi = (row_out && in_cone(r, a.cone_out, 1)) ? io.v_out_hi : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any((rc.vout != kOutOfRange) | (rc.vout_hi != kOutOfRange)) ? 1 : 0) != 0;
@@ -817,28 +819,38 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // pair, row nr does not (its next costs are zero or stale), rows beyond nr (kChroma only) have no
     // interpolated line either.  (Specialising the whole sweep on role.edge_wave -- two copies of the loop, no
     // branch per buffer step -- was tried: the register allocator then spills in both copies.)
-    if constexpr (MODE == kBand) {
+    if constexpr (BAND) {
         // the state the band holds on entering a row, as the next row's sweep sees it: real columns only
         auto leave_state = [&](int which) {
             const unsigned real_mask = (real[0] ? kLo : 0u) | (real[1] ? kHi : 0u);
             uint32_t* to = a.band_state + ((int64_t)(f * a.nbands + (int)blockIdx.y) * 2 + which) * (kBuffers * PXL * NW * 64) + tid;
 #pragma unroll
-            for (int b = 0; b < kBuffers; ++b)
+            for (int b = 0; b < kRegBuffers; ++b)
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * (NW * 64)] = A[b][j] & real_mask;
+#pragma unroll
+            for (int b = kRegBuffers; b < kBuffers; ++b) {
+                unsigned t[PXL];
+                load_A(parked, tid, b, t);
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * (NW * 64)] = t[j] & real_mask;
+            }
         };
-        for (int r = r0; r < ra; ++r) {
+        // run-up rows (nothing interpolated), then the band's own rows; row nr has no following line pair
+        static_assert(!has_pools(MODE), "the pool-coupled sweeps are not cut (sn_fused_v3_common.h)");
+        int r = r0;
+        for (; r < ra; ++r) {
             step(r, L1, L0, T{}, F{});
             L1 = L0;
         }
         leave_state(0);
-        const int re = bottom ? nr - 1 : rb;
-        for (int r = ra; r <= re; ++r) {
+        const int own_next = rb < nr ? rb + 1 : nr;
+        for (; r < own_next; ++r) {
             step(r, L1, L0, T{}, T{});
             L1 = L0;
         }
-        if (bottom) step(nr, L1, L0, F{}, T{});
-        else leave_state(1);
+        if (rb == nr) step(nr, L1, L0, F{}, T{});
+        if (rb < last) leave_state(1);
     } else {
         for (int r = 1; r < nr; ++r) {
             step(r, L1, L0, T{}, T{});
@@ -846,7 +858,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         }
         if (nr >= 1) step(nr, L1, L0, F{}, T{});
         if constexpr (chroma_mode(MODE)) {
-            for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+            for (int r = nr + 1; r <= last; ++r) step(r, L1, L0, F{}, F{});
         }
     }
 
@@ -864,7 +876,7 @@ static int virtual_waves_for(int nl) { return strips_for(nl); }
 // This file is compiled twice (csrc/Makefile).  The sweeps of planes on their own (kPlain, kPadded) go into an object
 // of their own, built with -mllvm -amdgpu-sched-strategy=max-ilp: +1.7 % on them, but that scheduler makes the
 // pool-coupled modes (which live at the register limit) spill, so those keep the default one.
-template <int MODE>
+template <int MODE, bool BAND = false>
 static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
 {
     const int g = v3c::group_of(a.nw);
@@ -873,9 +885,9 @@ static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
 #define SN_LAUNCH(NW)                                                                                              \
     case NW:                                                                                                       \
         if (lds > 64 * 1024)                                                                                       \
-            e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            e = hipFuncSetAttribute((const void*)v3::k_fused_u8_v3<NW, MODE, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         if (e == hipSuccess)                                                                                       \
-            hipLaunchKernelGGL((v3::k_fused_u8_v3<NW, MODE>), dim3((nframes + g - 1) / g, MODE == v3::kBand ? a.nbands : 1), dim3(NW * g * 64), lds, st, a); \
+            hipLaunchKernelGGL((v3::k_fused_u8_v3<NW, MODE, BAND>), dim3((nframes + g - 1) / g, BAND ? a.nbands : 1), dim3(NW * g * 64), lds, st, a); \
         break;
     switch (a.nw) {
         SN_LAUNCH(1) SN_LAUNCH(2) SN_LAUNCH(3) SN_LAUNCH(4) SN_LAUNCH(5) SN_LAUNCH(6) SN_LAUNCH(7) SN_LAUNCH(8)
@@ -889,7 +901,7 @@ static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
 #ifdef SN_TU_PLAIN
 hipError_t launch_fused_u8_v3_plain(hipStream_t st, const v3c::Args& a, int nframes, int mode)
 {
-    if (mode == v3::kBand) return launch_mode<v3::kBand>(st, a, nframes);
+    if (a.nbands > 1) return mode == v3::kPlain ? launch_mode<v3::kPlain, true>(st, a, nframes) : hipErrorInvalidValue;  // only planes on their own are cut
     return mode == v3::kPadded ? launch_mode<v3::kPadded>(st, a, nframes) : launch_mode<v3::kPlain>(st, a, nframes);
 }
 #else
@@ -940,7 +952,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.dst_frame_stride = p.dst_frame_stride;
     a.src_pitch = p.src_pitch;
     a.dst_pitch = p.dst_pitch;
-    a.w = pool && pool->mode != v3::kBand ? pool->sweep_w : p.w;
+    a.w = pool && pool->mode != v3::kPlain ? pool->sweep_w : p.w;
     a.nk = p.h_out / 2;
     a.offset = p.offset;
     a.dh = p.dh;
@@ -954,14 +966,15 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
     a.nframes = nframes;
     if (!pool) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPlain);
-    if (pool->mode == v3::kBand) {
+    if (pool->nbands > 1) {
         a.band_rows = pool->band_rows;
         a.band_warm = pool->band_warm;
         a.nbands = pool->nbands;
         a.band_state = pool->band_state;
         a.band_flags = pool->band_flags;
-        return launch_fused_u8_v3_plain(st, a, nframes, v3::kBand);
+        a.band_reset = pool->band_reset;
     }
+    if (pool->mode == v3::kPlain) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPlain);
     a.pool_in = pool->pool_in;
     a.pool_out = pool->pool_out;
     a.pool_frame_stride = pool->frame_stride;
@@ -974,8 +987,9 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.cone_nr = pool->cone_nr;
     a.cone_in = pool->cone_in;
     a.cone_out = pool->cone_out;
-    if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
     if (pool->mode == v3::kPadded) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPadded);
+    if (a.nbands > 1) return hipErrorInvalidValue;  // the pool-coupled sweeps are not cut (sn_fused_v3_common.h)
+    if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
     if (!pool->pool_out) return launch_mode<v3::kChromaLast>(st, a, nframes);
     return launch_mode<v3::kChroma>(st, a, nframes);
 }

@@ -56,12 +56,13 @@ struct Args {
     int32_t sweep_rows;       // kChroma: pool rows to sweep (>= nk - 1)
     int32_t turn_shift;       // log2 of the priority time slice in 100 MHz ticks (TurnTaking)
     int32_t nframes;          // frames of this launch (the last workgroup may hold fewer than group_of(nw))
-    // row bands (mode kBand): blockIdx.y = band; see below
+    // row bands (kernel template parameter BAND): blockIdx.y = band; see below
     int32_t band_rows;        // pool rows per band
     int32_t band_warm;        // rows a band sweeps before its first own row, starting from a zero guess of the state
     int32_t nbands;
     uint32_t* band_state;     // [frame][band][warm, end][kBuffers * PXL][threads of the plane] state words, ghosts zeroed
-    int32_t* band_flags;      // [frame]: reset here, set by the verification that follows (sn_band.hip)
+    int32_t* band_flags;      // [frame]: set by the verification that follows (sn_band.hip)
+    int32_t band_reset;       // this sweep clears band_flags first (the first plane of a frame)
 };
 
 // The reference's nine buffers are sized for the luma plane and shared by all planes, so a
@@ -78,16 +79,21 @@ struct Args {
 //               the whole stride, costs are zero in the padding columns, nothing is read back or left behind.
 //   kChromaLast the last chroma sweep of a frame: kChroma that hands nothing on (8-bit sweep only: no packing of stores
 //               that would all be dropped)
-//   kBand       a plane on its own cut into bands of rows, one workgroup per band, so that ONE frame fills the device (the
-//               latency path: a synchronous GetFrame, a short look-ahead).  Stage 2 is a recurrence from the top of
-//               the plane, so a band cannot know its starting state; but the recurrence forgets (each row keeps 7/16
-//               of the previous one), so the band starts `band_warm` rows early from a zero state and has, on ordinary
-//               content, the exact state when it reaches its own rows.  "Ordinary" is not "always" (a rounding
-//               difference of one can live on for ever on flat or periodic content), so every band leaves the state it
-//               reached its first row with and the state it ends with; sn_band.hip compares each band's end with the
-//               next band's start -- equal everywhere means, by induction from band 0, that every band was exact --
-//               and a frame that fails is redone by the pool path (guarded launches that otherwise exit at once).
-enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2, kPadded = 3, kChromaLast = 4, kBand = 5 };
+// Row bands (BAND, every mode): the plane is cut into bands of rows, one workgroup per band, so that ONE frame fills the
+// device (the latency path: a synchronous GetFrame, a short look-ahead).  Stage 2 is a recurrence from the top of the
+// plane, so a band cannot know its starting state; but the recurrence forgets (each row keeps 7/16 of the previous
+// one), so the band starts `band_warm` rows early from a zero state and has, on ordinary content, the exact state when
+// it reaches its own rows.  "Ordinary" is not "always" (a rounding difference of one can live on for ever on flat or
+// periodic content), so every band leaves the state it reached its first row with and the state it ends with;
+// sn_band.hip compares each band's end with the next band's start -- equal everywhere means, by induction from band 0,
+// that every band computed what the top-to-bottom sweep computes -- and a frame that fails is redone by the pool path
+// (guarded launches that otherwise exit at once). 
+// Only planes on their own are cut (kPlain, kPadded).  The pool-coupled sweeps were tried and work mechanically -- a band
+// starts from the hand-off row of its first row and hands on its own rows only -- but the last chroma sweep never passes
+// the check: outside the chroma region it re-smooths what two passes have smoothed already, data so even that the
+// rounding difference between the run-up and the true history does not die out (256 x 400 noise needs a run-up of 128
+// rows, 3840 x 2160 is still wrong after 128), so every such frame would be done twice.
+enum Mode { kPlain = 0, kLumaSpill = 1, kChroma = 2, kPadded = 3, kChromaLast = 4 };
 __host__ __device__ constexpr bool chroma_mode(int mode) { return mode == kChroma || mode == kChromaLast; }
 __host__ __device__ constexpr bool has_region(int mode) { return chroma_mode(mode) || mode == kPadded; }  // lines narrower than the sweep
 __host__ __device__ constexpr bool has_pools(int mode) { return mode == kLumaSpill || chroma_mode(mode); }

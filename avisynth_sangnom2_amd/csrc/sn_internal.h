@@ -61,7 +61,7 @@ bool fused_layout_ok(const PlaneArgs& p);
 bool fused_v3_plane_ok(int w);
 // Scratch-pool coupling between the luma sweep and the subsampled-chroma sweeps (sn_fused_u8_v3.hip, Mode).
 struct FusedPool {
-    int mode;                // 1 = luma sweep that leaves its smoothed rows, 2 = chroma sweep, 3 = padded plane (no pools)
+    int mode;                // 0 = plane on its own, 1 = luma sweep that leaves its smoothed rows, 2 = chroma sweep, 3 = padded plane (no pools)
     int sweep_w;             // luma width (the pool's width)
     const uint8_t* pool_in;  // chroma: what the previous pass left
     uint8_t* pool_out;       // luma / first chroma pass: where this pass leaves its rows (may be null)
@@ -71,14 +71,14 @@ struct FusedPool {
     int sweep_rows;          // chroma: pool rows to sweep
     int cone_w, cone_nr;     // the chroma plane's width and interpolated lines (dependency cone of the hand-off, Args)
     int cone_in, cone_out;   // extra columns: what this pass loads / stores beyond the final pass's cone
-    // mode 5 (kBand): a plane on its own in bands of rows (sn_fused_v3_common.h); verified by launch_band_verify
-    int band_rows, band_warm, nbands;
+    // nbands > 1: the sweep is cut into bands of rows (sn_fused_v3_common.h); to be verified by launch_band_verify
+    int band_rows, band_warm, nbands, band_reset;
     uint32_t* band_state;    // nframes * band_state_words(threads, nbands) words
     int32_t* band_flags;     // one per frame
 };
 // sn_band.hip: words of band state per frame for a sweep of `threads` threads; the check of a band launch -- flags[f] != 0
 // afterwards means frame f has to be redone by the pool path (its guarded launches look at the same flags);
-// *fallbacks (host-visible, may be null) counts such frames.
+// *fallbacks (device memory, may be null) counts such frames.
 inline int64_t band_state_words(int threads, int nbands) { return (int64_t)nbands * 2 * kBuffers * 8 * threads; }
 hipError_t launch_band_verify(hipStream_t s, const uint32_t* state, int threads, int nbands, int nframes, int32_t* flags, int64_t* fallbacks);
 int fused_v3_waves(int sweep_w);

@@ -691,9 +691,10 @@ def test_legacy_sangnom_wrapper_and_single_frame_device_entry(hip_lib):
 @pytest.mark.small_launch_policy
 @pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 3840, 2160, {}), ("YUV420P8", 1920, 1080, dict(aac=48)), ("Y16", 1920, 1080, {}),
                                         ("YUV420P8", 720, 480, dict(aac=48, fresh_pool=True))])
-def test_small_launches_take_the_pool_path_and_large_ones_the_sweeps(hip_lib, fmt, w, h, kw):
-    """SN_MODE_AUTO: one frame goes through the pool kernels, a launch of a whole round of workgroups through the
-    fused sweeps; same bytes either way."""
+def test_small_launches_take_the_pool_path_or_row_bands_and_large_ones_the_sweeps(hip_lib, fmt, w, h, kw):
+    """SN_MODE_AUTO: one frame goes through the sweep cut into row bands (planes on their own) or through the pool
+    kernels (coupled 4:2:0, isolated planes), a launch of a whole round of workgroups through the whole-plane sweeps;
+    same bytes either way."""
     import torch
     clip = clip_format(fmt, w, h)
     dev = torch.device("cuda:0")
@@ -711,11 +712,14 @@ def test_small_launches_take_the_pool_path_and_large_ones_the_sweeps(hip_lib, fm
         torch.cuda.synchronize()
         flt.process_batch([s[:1] for s in src], one)
         flt.synchronize()
-        assert flt.info().fused_frames == 0, "a single frame should have taken the pool path"
+        banded = 1 if clip.planes == 1 else 0
+        info = flt.info()
+        assert (info.fused_frames, info.banded_frames) == (banded, banded), "a single frame: row bands for a plane on its own, else the pool path"
         out = [torch.zeros_like(s) for s in src]
         flt.process_batch(src, out)
         flt.synchronize()
-        assert flt.info().fused_frames == N, "a full launch should have taken the fused sweeps"
+        info = flt.info()
+        assert (info.fused_frames, info.banded_frames) == (N + banded, banded), "a full launch should have taken the whole-plane sweeps"
         for p in range(clip.planes):
             assert torch.equal(one[p][0], out[p][0]), f"plane {p}: the two paths disagree"
 
@@ -955,6 +959,19 @@ BAND_CASES = [
     ("Y8", 960, 270, dict(dh=True), 5, 0),
     ("YUV444P8", 320, 240, dict(aac=30), 6, 0),
     ("YUV420P8", 256, 256, dict(chroma=False), 6, 0),  # chroma copied
+    # 9..16-bit and float sweeps
+    ("Y16", 256, 400, {}, 0, 0),
+    ("Y10", 1056, 300, dict(order=2, aa=20), 4, 0),
+    ("Y16", 3840, 360, {}, 7, 0),
+    ("Y16", 64, 200, dict(dh=True), 6, 0),
+    ("YUV444P16", 320, 240, dict(aac=30), 6, 0),
+    ("Y32", 256, 400, {}, 0, 0),
+    ("Y32", 1056, 300, dict(order=2, aa=20), 4, 0),
+    ("Y32", 3840, 360, {}, 7, 0),
+    ("YUV444PS", 320, 240, dict(aac=30, dh=True), 6, 0),
+    # subsampled chroma: the coupled sweeps are not cut (the last chroma sweep never passes the check), such launches
+    # keep the pool path
+    ("YUV420P8", 256, 400, dict(aac=48), 0, 0),
 ]
 
 
@@ -974,12 +991,18 @@ def test_row_bands_match_oracle(hip_lib, monkeypatch, fmt, w, h, kw, bands, warm
             for p in range(len(want)):
                 assert same(want[p], got[p]), f"{pattern} frame {f} plane {p}: " + describe_diff(want[p], got[p])
         info = flt.info()
-        assert info.banded_frames == 3
+        coupled = clip.planes == 3 and (clip.subw or clip.subh) and kw.get("chroma", True)
+        if coupled:
+            assert info.banded_frames == 0
+        elif bands > 0:
+            assert info.banded_frames == 3
+        else:  # automatic: after a failed check the following launches skip the bands
+            assert 1 <= info.banded_frames <= 3 and (info.banded_frames == 3 or info.band_fallbacks > 0)
         if pattern == "noise" and warm == 0:
             assert info.band_fallbacks == 0  # the default run-up is long enough for noise
 
 
-@pytest.mark.parametrize("fmt,w,h", [("Y8", 512, 300), ("Y8", 3840, 2160)])
+@pytest.mark.parametrize("fmt,w,h", [("Y8", 512, 300), ("Y8", 3840, 2160), ("Y16", 512, 300), ("Y32", 512, 300)])
 def test_row_bands_that_fail_the_check_are_redone(hip_lib, monkeypatch, fmt, w, h):
     """A run-up of one row leaves nearly every band with a wrong state: the check must notice and the pool path must
     repair every such frame."""
@@ -998,3 +1021,22 @@ def test_row_bands_that_fail_the_check_are_redone(hip_lib, monkeypatch, fmt, w, 
         got = flt.get_frame(src)
         assert same(want[0], got[0])
         assert flt.info().banded_frames == 2
+
+
+def test_row_bands_pause_after_failed_checks(hip_lib, monkeypatch):
+    """Content on which the run-up does not forget the guessed state (a checkerboard) would pay for the bands and for the
+    pool path every time: after a failed check the next launches skip the bands."""
+    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
+    clip = clip_format("Y8", 512, 400)
+    ora = Oracle(oracle_cfg(clip))
+    src = synth.frame(clip, "checker", seed=2)
+    want = ora.process(src)
+    with SangNom2(clip) as flt:
+        banded = []
+        for f in range(12):
+            got = flt.get_frame(src)
+            assert same(want[0], got[0]), f"frame {f}"
+            banded.append(flt.info().banded_frames)
+        info = flt.info()
+        if info.band_fallbacks:  # the first frame failed its check: the next eight launches skip the bands, then one more try
+            assert banded[0] == banded[8] == 1 and info.banded_frames <= 2
