@@ -515,7 +515,13 @@ static int band_warm_rows(const Context* c)
 // Bands per frame for a launch of n frames on slots slot0.., 0 = do not cut.
 static int band_count(Context* c, int n, int slot0)
 {
-    if (c->band_force < 0 || c->cfg.mode != SN_MODE_AUTO || !c->use_fused || c->fused420 || c->isolated || !c->history_free) return 0;
+    if (c->band_force < 0 || c->cfg.mode != SN_MODE_AUTO || c->fused420 || !c->history_free) return 0;
+    if (c->isolated) {  // every processed plane must have the sweep for planes on their own (not the padded one)
+        for (int p = 0; p < c->nplanes(); ++p)
+            if ((c->cfg.dh || c->process[p]) && (!c->plane_fused[p] || c->plane_padded[p])) return 0;
+    } else if (!c->use_fused) {
+        return 0;
+    }
     if (slot0 + n > c->slots) return 0;  // the fallback needs the frames' pool slots
     if (c->band_force == 0)
         if (const char* e = getenv("SN_PREFER_POOL"))  // 0: whole-plane sweeps always (see prefer_pool)
@@ -625,6 +631,46 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         return sn::launch_fused_u8_v3(st, a, c->threshold(p), m, nullptr);
     };
 
+    // The latency path of one plane: bands, their check, and the pool path for the frames that fail it (its launches
+    // exit at once otherwise).
+    auto banded_plane = [&](int p, sn::PlaneArgs a, sn::PoolArgs pool) -> int {
+        sn::FusedPool fp{};
+        fp.mode = 0;  // kPlain, in bands
+        set_bands(c, fp, nbands, a.h_out / 2 - 1, slot0, true);
+        const int B = c->cfg.bytes_per_sample;
+        if (B == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, &fp));
+        else if (B == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
+        else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp));
+        const int threads = 64 * (B == 4 ? sn::fused_f32_waves(a.w) : B == 2 ? sn::fused_u16_waves(a.w) : sn::fused_v3_waves(a.w));
+        SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks_dev));
+        a.guard = fp.band_flags;
+        pool.guard = fp.band_flags;
+        SN_HIP(c, sn::launch_assemble(st, a, B, n));
+        SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(p), n, slot0));
+        return SN_OK;
+    };
+
+    if (c->isolated && nbands) {
+        int rc = ensure_bands(c);
+        if (rc != SN_OK) return rc;
+        for (int p = 0; p < c->nplanes(); ++p) {
+            if (!pa[p].enabled) {
+                SN_HIP(c, sn::launch_assemble(st, pa[p], c->cfg.bytes_per_sample, n));
+                continue;
+            }
+            rc = ensure_pool(c, p);
+            if (rc != SN_OK) return rc;
+            const sn::PoolArgs& pool = c->plane_pool[p];
+            if (c->fresh) SN_HIP(c, hipMemsetAsync(pool.base + (int64_t)slot0 * pool.slot_bytes, 0, (size_t)pool.slot_bytes * n, st));
+            rc = banded_plane(p, pa[p], pool);
+            if (rc != SN_OK) return rc;
+        }
+        SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        c->fused_frames += n;
+        c->banded_frames += n;
+        return SN_OK;
+    }
+
     if (c->isolated) {  // every plane on its own: plain fused sweep or the pool path over the plane's own pool
         bool counted = false;
         for (int p = 0; p < c->nplanes(); ++p) {
@@ -713,20 +759,8 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
                 SN_HIP(c, sn::launch_assemble(st, a, c->cfg.bytes_per_sample, n));
                 continue;
             }
-            sn::FusedPool fp{};
-            fp.mode = 0;  // kPlain, in bands
-            set_bands(c, fp, nbands, a.h_out / 2 - 1, slot0, true);
-            const int B = c->cfg.bytes_per_sample;
-            if (B == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), n, &fp));
-            else if (B == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
-            else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp));
-            const int threads = 64 * (B == 4 ? sn::fused_f32_waves(a.w) : B == 2 ? sn::fused_u16_waves(a.w) : sn::fused_v3_waves(a.w));
-            SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks_dev));
-            a.guard = fp.band_flags;
-            sn::PoolArgs pool = c->pool;
-            pool.guard = fp.band_flags;
-            SN_HIP(c, sn::launch_assemble(st, a, B, n));
-            SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(p), n, slot0));
+            rc = banded_plane(p, a, c->pool);
+            if (rc != SN_OK) return rc;
         }
         SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         c->fused_frames += n;
@@ -752,12 +786,27 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     // pass left in the slot (SangNom2.cpp:322-329).
     int rc = ensure_pool(c);
     if (rc != SN_OK) return rc;
+    // The reference smooths the whole luma-sized pool in every pass (SangNom2.cpp:126-159).  A plane of fewer lines reads
+    // back only rows 1 .. nr of it, and a later pass of this frame reads one row further than it smooths -- when nothing
+    // is carried into the next frame, rows beyond that are never looked at again and stage 2 stops there (4:2:0: the
+    // two chroma passes take half the time).  SN_MODE_POOL keeps the full emulation, pool contents included.
+    int stop[3] = {0, 0, 0};
+    if (c->history_free && c->cfg.mode != SN_MODE_POOL) {
+        int later = 0;
+        for (int p = c->nplanes() - 1; p >= 0; --p) {
+            if (!pa[p].enabled) continue;
+            const int own = pa[p].h_out / 2;  // rows 1 .. nr = own - 1
+            stop[p] = own > later + 1 ? own : later + 1;
+            later = stop[p];
+        }
+    }
     for (int i = 0; i < n; i += c->slots) {
         const int m = n - i < c->slots ? n - i : c->slots;
         for (int p = 0; p < c->nplanes(); ++p) {
             if (!pa[p].enabled || (fused[p] && !c->fused420)) continue;
-            SN_HIP(c, sn::launch_pool_plane(st, frames_from(pa[p], i), c->pool, c->cfg.bytes_per_sample,
-                                            c->threshold(p), m, slot0));
+            sn::PoolArgs pool = c->pool;
+            pool.rows = stop[p];
+            SN_HIP(c, sn::launch_pool_plane(st, frames_from(pa[p], i), pool, c->cfg.bytes_per_sample, c->threshold(p), m, slot0));
         }
     }
     return SN_OK;

@@ -35,6 +35,7 @@ struct PoolArgs {
     int32_t stride_e;          // roundup(luma width, 32)
     int32_t bh;                // bufferHeight; a buffer has bh + 1 rows
     const int32_t* guard;      // as PlaneArgs::guard
+    int32_t rows;              // stage 2 stops before this pool row (0 = bh: the whole pool, as the reference does)
 };
 
 struct Context;

@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
     load(0, prev);
     load(1, cur);
     load(row_or_last(2), nxt);
-    for (int r = 1; r < pool.bh; ++r) {
+    const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    for (int r = 1; r < rows; ++r) {
         W pre[NC];  // row r+2, fetched one row step ahead of its first use (unconditional: a branch around the load
         load(row_or_last(r + 2), pre);  // makes the compiler wait for it at once)
         W* line = (r & 1) ? line1 : line0;
@@ -232,7 +233,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_strided(PoolArgs pool
         cur[k] = in ? (W)buf[(size_t)se + x] : (W)0;
         nxt[k] = (in && pool.bh >= 2) ? (W)buf[(size_t)2 * se + x] : (W)0;
     }
-    for (int r = 1; r < pool.bh; ++r) {
+    const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    for (int r = 1; r < rows; ++r) {
         W pre[NC];
 #pragma unroll
         for (int k = 0; k < NC; ++k) {

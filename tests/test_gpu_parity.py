@@ -1040,3 +1040,23 @@ def test_row_bands_pause_after_failed_checks(hip_lib, monkeypatch):
         info = flt.info()
         if info.band_fallbacks:  # the first frame failed its check: the next eight launches skip the bands, then one more try
             assert banded[0] == banded[8] == 1 and info.banded_frames <= 2
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", [("YUV420P8", 512, 400, dict(aac=48)), ("YUV420P16", 256, 320, dict(aac=48, fresh_pool=True)),
+                                        ("YUV422PS", 256, 256, dict(aac=48))])
+def test_row_bands_serve_isolated_planes(hip_lib, monkeypatch, fmt, w, h, kw):
+    """isolated_planes: every plane is a plane on its own, so single frames are cut into row bands too (4:2:0 included);
+    same bytes as the whole-plane sweeps."""
+    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
+    clip = clip_format(fmt, w, h)
+    frames = make_frames(clip, "noise", 3, seed0=17)
+    with SangNom2(clip, isolated_planes=True, **kw) as flt:
+        got = [flt.get_frame(src, parity=f & 1) for f, src in enumerate(frames)]
+        info = flt.info()
+        assert (info.banded_frames, info.band_fallbacks) == (3, 0)
+    with SangNom2(clip, isolated_planes=True, mode="fused", **kw) as flt:
+        want = [flt.get_frame(src, parity=f & 1) for f, src in enumerate(frames)]
+        assert flt.info().banded_frames == 0
+    for f in range(3):
+        for p in range(3):
+            assert same(want[f][p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
