@@ -216,6 +216,36 @@ static bool compute_history_free(const Context& c)
 using sn::Context;
 using sn::Copier;
 
+#ifdef SN_ABORT_TRACE  // diagnostic builds only (make EXTRA=-DSN_ABORT_TRACE): where did an abort() come from?
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void abort_trace(int sig)
+{
+    const int fd = open("gpurun_out/abort_trace.txt", O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (fd >= 0) {
+        void* frames[64];
+        const int n = backtrace(frames, 64);
+        dprintf(fd, "signal %d, %d frames\n", sig, n);
+        backtrace_symbols_fd(frames, n, fd);
+        close(fd);
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct AbortTraceInstaller {
+    AbortTraceInstaller()
+    {
+        signal(SIGABRT, abort_trace);
+        signal(SIGSEGV, abort_trace);
+        signal(SIGBUS, abort_trace);
+    }
+} g_abort_trace_installer;
+}  // namespace
+#endif
+
 #pragma GCC visibility push(default)
 extern "C" {
 
@@ -515,7 +545,7 @@ static int band_warm_rows(const Context* c)
 // Bands per frame for a launch of n frames on slots slot0.., 0 = do not cut.
 static int band_count(Context* c, int n, int slot0)
 {
-    if (c->band_force < 0 || c->cfg.mode != SN_MODE_AUTO || c->fused420 || !c->history_free) return 0;
+    if (c->band_force < 0 || c->cfg.mode != SN_MODE_AUTO || !c->history_free) return 0;
     if (c->isolated) {  // every processed plane must have the sweep for planes on their own (not the padded one)
         for (int p = 0; p < c->nplanes(); ++p)
             if ((c->cfg.dh || c->process[p]) && (!c->plane_fused[p] || c->plane_padded[p])) return 0;
@@ -619,6 +649,20 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     const int nbands = all_fused ? band_count(c, n, slot0) : 0;
     if (nbands == 0 && prefer_pool(c, n, slot0))
         for (int p = 0; p < 3; ++p) fused[p] = false;
+    // The reference smooths the whole luma-sized pool in every pass (SangNom2.cpp:126-159).  A plane of fewer lines reads
+    // back only rows 1 .. nr of it, and a later pass of this frame reads one row further than it smooths -- when nothing
+    // is carried into the next frame, rows beyond that are never looked at again and stage 2 of the pool path stops
+    // there (4:2:0: the two chroma passes take half the time).  SN_MODE_POOL keeps the full emulation, pool contents included.
+    int stop[3] = {0, 0, 0};
+    if (c->history_free && c->cfg.mode != SN_MODE_POOL) {
+        int later = 0;
+        for (int p = c->nplanes() - 1; p >= 0; --p) {
+            if (!pa[p].enabled) continue;
+            const int own = pa[p].h_out / 2;  // rows 1 .. nr = own - 1
+            stop[p] = own > later + 1 ? own : later + 1;
+            later = stop[p];
+        }
+    }
     auto frames_from = [](sn::PlaneArgs a, int i) {
         a.src += (int64_t)i * a.src_frame_stride;
         a.dst += (int64_t)i * a.dst_frame_stride;
@@ -711,6 +755,45 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     // Fused 4:2:0: the luma sweep leaves its smoothed rows in hand-off pool 0, U reads pool 0 and leaves pool 1,
     // V reads pool 1 -- so the three sweeps of a chunk of frames run back to back on that chunk's pools.
     const bool coupled = c->fused420 && fused[0] && fused[1] && fused[2];
+    if (coupled && nbands) {
+        // A small launch of a 4:2:0 clip: the luma plane in bands, leaving its smoothed rows where the pool path's luma
+        // pass would (the chroma sweeps of the coupling cannot be cut: sn_fused_v3_common.h); the luma plane of a
+        // frame that fails the check is redone by the pool kernels; then the chroma planes by the pool kernels.
+        int rc = ensure_bands(c);
+        if (rc == SN_OK) rc = ensure_pool(c);
+        if (rc != SN_OK) return rc;
+        const int B = c->cfg.bytes_per_sample;
+        sn::FusedPool fp{};
+        fp.mode = 1;  // kLumaSpill
+        fp.sweep_w = c->cfg.width;
+        fp.pool_out = c->pool.base + (int64_t)slot0 * c->pool.slot_bytes;
+        fp.frame_stride = c->pool.slot_bytes;
+        fp.pool_rows = c->bh + 1;
+        fp.pool_row_bytes = c->stride_e * B;
+        fp.rows_out = stop[1] < c->bh - 1 ? stop[1] : c->bh - 1;  // what U's stage 2 reads: rows up to the one it stops at
+        fp.cone_nr = 1 << 20;  // every column is kept
+        set_bands(c, fp, nbands, pa[0].h_out / 2 - 1, slot0, true);
+        if (B == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, pa[0], c->threshold(0), n, &fp));
+        else if (B == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, pa[0], c->threshold(0), n, &fp));
+        else SN_HIP(c, sn::launch_fused_u8_v3(st, pa[0], c->threshold(0), n, &fp));
+        SN_HIP(c, sn::launch_band_verify(st, fp.band_state, band_threads(c), fp.nbands, n, fp.band_flags, c->band_fallbacks_dev));
+        SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        sn::PlaneArgs a = pa[0];
+        a.guard = fp.band_flags;
+        sn::PoolArgs pool = c->pool;
+        pool.guard = fp.band_flags;
+        pool.rows = stop[0];
+        SN_HIP(c, sn::launch_assemble(st, a, B, n));
+        SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(0), n, slot0));
+        for (int p = 1; p < 3; ++p) {
+            pool = c->pool;
+            pool.rows = stop[p];
+            SN_HIP(c, sn::launch_assemble(st, pa[p], B, n));
+            SN_HIP(c, sn::launch_pool_plane(st, pa[p], pool, B, c->threshold(p), n, slot0));
+        }
+        c->banded_frames += n;
+        return SN_OK;
+    }
     if (coupled) {
         const int nr_c = c->plane_h_out(1) / 2 - 1;
         const int reach = c->fpool_rows - 1;
@@ -786,20 +869,6 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     // pass left in the slot (SangNom2.cpp:322-329).
     int rc = ensure_pool(c);
     if (rc != SN_OK) return rc;
-    // The reference smooths the whole luma-sized pool in every pass (SangNom2.cpp:126-159).  A plane of fewer lines reads
-    // back only rows 1 .. nr of it, and a later pass of this frame reads one row further than it smooths -- when nothing
-    // is carried into the next frame, rows beyond that are never looked at again and stage 2 stops there (4:2:0: the
-    // two chroma passes take half the time).  SN_MODE_POOL keeps the full emulation, pool contents included.
-    int stop[3] = {0, 0, 0};
-    if (c->history_free && c->cfg.mode != SN_MODE_POOL) {
-        int later = 0;
-        for (int p = c->nplanes() - 1; p >= 0; --p) {
-            if (!pa[p].enabled) continue;
-            const int own = pa[p].h_out / 2;  // rows 1 .. nr = own - 1
-            stop[p] = own > later + 1 ? own : later + 1;
-            later = stop[p];
-        }
-    }
     for (int i = 0; i < n; i += c->slots) {
         const int m = n - i < c->slots ? n - i : c->slots;
         for (int p = 0; p < c->nplanes(); ++p) {

@@ -449,8 +449,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     // scratch pools of the chroma coupling
     PoolIO io{};
     if constexpr (has_pools(MODE)) {
-        const int pool_bytes = kBuffers * a.pool_rows * NT * 32;
-        io.row_stride = NT * 32;
+        const bool linear = MODE == kLumaSpill && a.pool_row_bytes > 0;  // the pool path's layout
+        io.row_stride = linear ? a.pool_row_bytes : NT * 32;
+        const int pool_bytes = kBuffers * a.pool_rows * io.row_stride;
         io.buf_stride = a.pool_rows * io.row_stride;
         if (chroma_mode(MODE))
             io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in ? a.pool_in + (int64_t)f * a.pool_frame_stride : nullptr), 0,
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         if (lane < GH && wave > 0) ta = (wave - 1) * 64 + (64 - 2 * GH) + lane;
         if (lane >= 64 - GH && wave < NW - 1) ta = (wave + 1) * 64 + GH + (lane - (64 - GH));
         io.v_a = ta * 32;
-        io.v_out = real ? tid * 32 : kOutOfRange;
+        io.v_out = real ? (linear ? x0 * 4 : tid * 32) : kOutOfRange;
     }
     // Does this lane's slot of pool row q matter (Args::cone_*)?  Its first column is 8 * lane + 480 * wave.
     auto in_cone = [&](int q, int extra) -> bool {
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     const int nk = a.nk;
     const int nr = nk - 1;
     // BAND (planes on their own only, sn_fused_v3_common.h): own rows ra .. rb, swept from row r0 on
-    static_assert(!(BAND && has_pools(MODE)), "the pool-coupled sweeps are not cut");
+    static_assert(!(BAND && chroma_mode(MODE)), "the chroma sweeps of the coupling are not cut");
     int r0 = 1, ra = 1, rb = nr;
     if constexpr (BAND) {
         ra = 1 + (int)blockIdx.y * a.band_rows;
@@ -637,7 +638,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         rc.any_out = false;
         if constexpr (chroma_mode(MODE)) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
         if constexpr (has_pools(MODE)) {
-            rc.vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
+            rc.vout = (r <= a.rows_out && (!BAND || r >= ra) && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
         }
         const Out o = row_step<S1, S3, MODE>(A, parked, tid, n, nn, role, aaf, io, rc);
@@ -794,7 +795,7 @@ hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double thresh
         a.band_flags = pool->band_flags;
         a.band_reset = pool->band_reset;
         if (pool->mode == v3c::kPlain) return f32::launch_mode<v3c::kPlain, true>(st, a, aaf, nframes);
-        return hipErrorInvalidValue;  // only planes on their own are cut
+        if (pool->mode != v3c::kLumaSpill) return hipErrorInvalidValue;  // of the pool-coupled sweeps only the luma one is cut
     }
     if (pool->mode == v3c::kPlain) return f32::launch_mode<v3c::kPlain>(st, a, aaf, nframes);
     if (pool->mode == v3c::kPadded) return f32::launch_mode<v3c::kPadded>(st, a, aaf, nframes);
@@ -809,6 +810,8 @@ hipError_t launch_fused_f32_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.cone_nr = pool->cone_nr;
     a.cone_in = pool->cone_in;
     a.cone_out = pool->cone_out;
+    a.pool_row_bytes = pool->mode == v3c::kLumaSpill ? pool->pool_row_bytes : 0;
+    if (pool->mode == v3c::kLumaSpill && a.nbands > 1) return f32::launch_mode<v3c::kLumaSpill, true>(st, a, aaf, nframes);
     if (pool->mode == v3c::kLumaSpill) return f32::launch_mode<v3c::kLumaSpill>(st, a, aaf, nframes);
     if (!pool->pool_out) return f32::launch_mode<v3c::kChromaLast>(st, a, aaf, nframes);
     return f32::launch_mode<v3c::kChroma>(st, a, aaf, nframes);

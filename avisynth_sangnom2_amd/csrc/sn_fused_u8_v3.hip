@@ -587,8 +587,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // scratch pools of the chroma coupling
     PoolIO io{};
     if constexpr (has_pools(MODE)) {
-        const int pool_bytes = kBuffers * a.pool_rows * NW * 64 * 16;
-        io.row_stride = NW * 64 * 16;
+        const bool linear = MODE == kLumaSpill && a.pool_row_bytes > 0;  // the pool path's layout
+        io.row_stride = linear ? a.pool_row_bytes : NW * 64 * 16;
+        const int pool_bytes = kBuffers * a.pool_rows * io.row_stride;
         io.buf_stride = a.pool_rows * io.row_stride;
         if (chroma_mode(MODE))
             io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.pool_in ? a.pool_in + (int64_t)f * a.pool_frame_stride : nullptr), 0,
@@ -611,8 +612,8 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         // cone write and read whole cache lines (interleaved with the other kind every line was half useful)
         io.v_lo = c_lo * (NW * 64 * 8) + t_lo * 8;
         io.v_hi = c_hi * (NW * 64 * 8) + t_hi * 8;
-        io.v_out_lo = real[0] ? tid * 8 : kOutOfRange;
-        io.v_out_hi = real[1] ? NW * 64 * 8 + tid * 8 : kOutOfRange;
+        io.v_out_lo = real[0] ? (linear ? x0[0] : tid * 8) : kOutOfRange;
+        io.v_out_hi = real[1] ? (linear ? x0[1] : NW * 64 * 8 + tid * 8) : kOutOfRange;
     }
 
     // Does a half of this lane matter in pool row q (Args::cone_*)?  Column of the low half: 8 * lane + 480 * wave, the
@@ -837,7 +838,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             }
         };
         // run-up rows (nothing interpolated), then the band's own rows; row nr has no following line pair
-        static_assert(!has_pools(MODE), "the pool-coupled sweeps are not cut (sn_fused_v3_common.h)");
+        static_assert(!chroma_mode(MODE), "the chroma sweeps of the coupling are not cut (sn_fused_v3_common.h)");
         int r = r0;
         for (; r < ra; ++r) {
             step(r, L1, L0, T{}, F{});
@@ -988,7 +989,11 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.cone_in = pool->cone_in;
     a.cone_out = pool->cone_out;
     if (pool->mode == v3::kPadded) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPadded);
-    if (a.nbands > 1) return hipErrorInvalidValue;  // the pool-coupled sweeps are not cut (sn_fused_v3_common.h)
+    a.pool_row_bytes = pool->mode == v3::kLumaSpill ? pool->pool_row_bytes : 0;
+    if (a.nbands > 1) {  // of the pool-coupled sweeps only the luma one is cut (sn_fused_v3_common.h)
+        if (pool->mode != v3::kLumaSpill) return hipErrorInvalidValue;
+        return launch_mode<v3::kLumaSpill, true>(st, a, nframes);
+    }
     if (pool->mode == v3::kLumaSpill) return launch_mode<v3::kLumaSpill>(st, a, nframes);
     if (!pool->pool_out) return launch_mode<v3::kChromaLast>(st, a, nframes);
     return launch_mode<v3::kChroma>(st, a, nframes);

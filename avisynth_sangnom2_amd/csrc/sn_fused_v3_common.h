@@ -50,6 +50,8 @@ struct Args {
     uint8_t* pool_out;        // where this pass leaves its smoothed buffers (kLumaSpill, first kChroma pass)
     int64_t pool_frame_stride;
     int32_t pool_rows;        // rows a pool buffer holds (row index 1 .. pool_rows - 1 used)
+    int32_t pool_row_bytes;   // 0: pool_out has the sweeps' own layout (a slot per thread); > 0 (kLumaSpill): it is a pool
+                              // of the pool path, [buffer][row][column] samples with this row pitch (sn_pool_kernels.hip)
     int32_t rows_in;          // rows 1 .. rows_in of pool_in are valid, later rows read as zero
     int32_t rows_out;         // rows 1 .. rows_out are written to pool_out (0 = none)
     int32_t region_w;         // kChroma: columns < region_w belong to the chroma plane
@@ -88,7 +90,9 @@ struct Args {
 // sn_band.hip compares each band's end with the next band's start -- equal everywhere means, by induction from band 0,
 // that every band computed what the top-to-bottom sweep computes -- and a frame that fails is redone by the pool path
 // (guarded launches that otherwise exit at once). 
-// Only planes on their own are cut (kPlain, kPadded).  The pool-coupled sweeps were tried and work mechanically -- a band
+// Planes on their own are cut (kPlain), and the luma sweep that leaves its rows in a pool of the POOL PATH
+// (kLumaSpill with pool_row_bytes): a single 4:2:0 frame takes its luma plane through the bands and its chroma planes
+// through the pool kernels, which find in the pool what the reference's luma pass would have left there.  The pool-coupled sweeps were tried and work mechanically -- a band
 // starts from the hand-off row of its first row and hands on its own rows only -- but the last chroma sweep never passes
 // the check: outside the chroma region it re-smooths what two passes have smoothed already, data so even that the
 // rounding difference between the run-up and the true history does not die out (256 x 400 noise needs a run-up of 128

@@ -68,6 +68,7 @@ struct FusedPool {
     uint8_t* pool_out;       // luma / first chroma pass: where this pass leaves its rows (may be null)
     int64_t frame_stride;    // bytes between the pools of consecutive frames
     int pool_rows;           // rows per pool buffer
+    int pool_row_bytes;      // > 0 (mode 1): pool_out is a pool of the pool path with this row pitch (Args::pool_row_bytes)
     int rows_in, rows_out;   // valid rows in pool_in / rows to write to pool_out
     int sweep_rows;          // chroma: pool rows to sweep
     int cone_w, cone_nr;     // the chroma plane's width and interpolated lines (dependency cone of the hand-off, Args)

@@ -712,14 +712,17 @@ def test_small_launches_take_the_pool_path_or_row_bands_and_large_ones_the_sweep
         torch.cuda.synchronize()
         flt.process_batch([s[:1] for s in src], one)
         flt.synchronize()
-        banded = 1 if clip.planes == 1 else 0
+        # a plane on its own: row bands; coupled 4:2:0: the luma plane in bands, chroma by the pool kernels (not counted as
+        # a fused frame); isolated planes of a width the sweeps only serve padded: the pool path
+        banded = 0 if kw.get("fresh_pool") else 1
+        fused1 = 1 if clip.planes == 1 else 0
         info = flt.info()
-        assert (info.fused_frames, info.banded_frames) == (banded, banded), "a single frame: row bands for a plane on its own, else the pool path"
+        assert (info.fused_frames, info.banded_frames) == (fused1, banded)
         out = [torch.zeros_like(s) for s in src]
         flt.process_batch(src, out)
         flt.synchronize()
         info = flt.info()
-        assert (info.fused_frames, info.banded_frames) == (N + banded, banded), "a full launch should have taken the whole-plane sweeps"
+        assert (info.fused_frames, info.banded_frames) == (N + fused1, banded), "a full launch should have taken the whole-plane sweeps"
         for p in range(clip.planes):
             assert torch.equal(one[p][0], out[p][0]), f"plane {p}: the two paths disagree"
 
@@ -969,9 +972,17 @@ BAND_CASES = [
     ("Y32", 1056, 300, dict(order=2, aa=20), 4, 0),
     ("Y32", 3840, 360, {}, 7, 0),
     ("YUV444PS", 320, 240, dict(aac=30, dh=True), 6, 0),
-    # subsampled chroma: the coupled sweeps are not cut (the last chroma sweep never passes the check), such launches
-    # keep the pool path
+    # subsampled chroma: the luma plane in bands (its smoothed rows go where the pool path's luma pass leaves them), the
+    # chroma planes through the pool kernels
     ("YUV420P8", 256, 400, dict(aac=48), 0, 0),
+    ("YUV420P8", 1056, 288, dict(aac=20, order=2), 5, 0),
+    ("YUV420P8", 3840, 400, dict(aac=48), 9, 0),
+    ("YUV420P8", 7680, 264, dict(aac=48), 4, 0),
+    ("YUV422P8", 576, 300, dict(aac=48), 6, 0),
+    ("YUV420P8", 640, 200, dict(aac=48, dh=True), 7, 0),
+    ("YUV420P8", 320, 240, dict(aac=48), 10, 1),       # a run-up of one row: luma redone by the pool path
+    ("YUV420P16", 512, 320, dict(aac=48), 6, 0),
+    ("YUV420PS", 256, 256, dict(aac=48, order=0), 5, 0),
 ]
 
 
@@ -991,10 +1002,7 @@ def test_row_bands_match_oracle(hip_lib, monkeypatch, fmt, w, h, kw, bands, warm
             for p in range(len(want)):
                 assert same(want[p], got[p]), f"{pattern} frame {f} plane {p}: " + describe_diff(want[p], got[p])
         info = flt.info()
-        coupled = clip.planes == 3 and (clip.subw or clip.subh) and kw.get("chroma", True)
-        if coupled:
-            assert info.banded_frames == 0
-        elif bands > 0:
+        if bands > 0:
             assert info.banded_frames == 3
         else:  # automatic: after a failed check the following launches skip the bands
             assert 1 <= info.banded_frames <= 3 and (info.banded_frames == 3 or info.band_fallbacks > 0)
