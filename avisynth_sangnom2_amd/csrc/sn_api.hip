@@ -619,6 +619,25 @@ static int ensure_bands(Context* c)
     return SN_OK;
 }
 
+// The host-facing entry points (a synchronous GetFrame, the host ring) launch a few frames at a time, i.e. they will
+// want the scratch of the small-launch paths: the pool-path pool and the band state.  It is allocated here, BEFORE the
+// call queues its copies from pageable host memory -- allocating in the middle of such a call (as the lazy
+// ensure_pool / ensure_bands of run_group would) puts hipMalloc / hipHostMalloc between the runtime's in-flight staging
+// of those copies and their completion.
+static int prepare_small_launch_scratch(Context* c)
+{
+    if (c->cfg.mode != SN_MODE_AUTO || !c->history_free) return SN_OK;
+    int rc = SN_OK;
+    if (c->isolated) {
+        for (int p = 0; p < c->nplanes() && rc == SN_OK; ++p)
+            if (c->cfg.dh || c->process[p]) rc = ensure_pool(c, p);
+    } else if (c->use_fused) {
+        rc = ensure_pool(c);
+    }
+    if (rc == SN_OK && c->band_force >= 0 && (c->isolated || c->use_fused)) rc = ensure_bands(c);
+    return rc;
+}
+
 // Runs frames [f0, f0 + n) of a strided batch with one common field offset.
 // `st` is the stream to launch on and `slot0` the first scratch slot the frames may use (the batch entry points
 // pass the context's stream and slot 0, the host ring one frame on its slot's stream and scratch).
@@ -934,6 +953,8 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     int rc = check_planes(c, src, sp, dst, dp);
     if (rc != SN_OK) return rc;
     SN_HIP(c, hipSetDevice(c->device));
+    rc = prepare_small_launch_scratch(c);
+    if (rc != SN_OK) return rc;
     const int B = c->cfg.bytes_per_sample;
     for (int p = 0; p < c->nplanes(); ++p) {
         if (!c->stage_src[p]) {
@@ -1079,6 +1100,7 @@ static int submit_impl(sn_context* h, const void* const src[3], const int32_t sp
     }
     SN_HIP(c, hipSetDevice(c->device));
     int rc = ensure_ring(c);
+    if (rc == SN_OK) rc = prepare_small_launch_scratch(c);
     if (rc != SN_OK) return rc;
     const int slot = c->ring_next;
     if (c->slot_state[slot] != Context::kFree)
@@ -1413,6 +1435,8 @@ int sn_aa_process_host(sn_aa_context* a, const void* const src[3], const int32_t
         if (rc_ != SN_OK) return bad(rc_, sn_last_error(ctx));              \
     } while (0)
     SN_AA_HIP(hipSetDevice(a->cfg.device));
+    SN_AA_SN(a->first, prepare_small_launch_scratch(reinterpret_cast<Context*>(a->first)));
+    SN_AA_SN(a->second, prepare_small_launch_scratch(reinterpret_cast<Context*>(a->second)));
     for (int p = 0; p < a->planes; ++p)
         SN_AA_HIP(hipMemcpy2DAsync(a->d_src[p], a->pitch[p], src[p], sp[p], (size_t)a->w[p] * B, a->h[p], hipMemcpyHostToDevice, a->stream));
     for (int p = 0; p < a->planes; ++p)  // TurnLeft
