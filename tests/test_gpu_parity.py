@@ -1068,3 +1068,47 @@ def test_row_bands_serve_isolated_planes(hip_lib, monkeypatch, fmt, w, h, kw):
     for f in range(3):
         for p in range(3):
             assert same(want[f][p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
+
+
+@pytest.mark.parametrize("fmt,w,h,kw,n", [("Y8", 512, 300, {}, 5), ("Y8", 64, 200, dict(order=0), 7), ("Y16", 1056, 240, dict(aa=20), 3),
+                                          ("YUV444PS", 256, 200, dict(aac=48), 4), ("YUV420P8", 512, 320, dict(aac=48), 6)])
+def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, h, kw, n):
+    """A launch of a few frames (a host ring group, a short device batch) is cut into bands as well: frames x bands
+    workgroups, one flag per frame.  One of the frames is a checkerboard, which may fail its check on its own."""
+    import torch
+    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
+    clip = clip_format(fmt, w, h)
+    frames = make_frames(clip, "noise", n, seed0=41)
+    frames[n // 2] = synth.frame(clip, "checker", seed=9)
+    parity = [(f * 3) & 1 for f in range(n)]
+    ora = Oracle(oracle_cfg(clip, **kw))
+    want = [ora.process(frames[f], parity=parity[f]) for f in range(n)]
+    dev = torch.device("cuda:0")
+    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
+    with SangNom2(clip, max_batch=n, **kw) as flt:
+        flt.set_bands(6, 0)
+        src = [torch.from_numpy(np.stack([frames[f][p] for f in range(n)]).view({1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes])).to(dev)
+               for p in range(clip.planes)]
+        dst = [torch.zeros((n,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
+        torch.cuda.synchronize()
+        flt.process_batch(src, dst, parity=parity)
+        flt.synchronize()
+        assert flt.info().banded_frames == n
+        for f in range(n):
+            for p in range(clip.planes):
+                got = dst[p][f].cpu().numpy().view(clip.dtype)
+                assert same(want[f][p], got), f"frame {f} plane {p}: " + describe_diff(want[f][p], got)
+    # the host ring: groups of one or two frames per launch
+    with SangNom2(clip, host_depth=4, **kw) as flt:
+        flt.set_bands(5, 0)
+        inflight, got = [], []
+        for f in range(n):
+            if len(inflight) == flt.host_slots():
+                got.append(flt.collect(inflight.pop(0)))
+            inflight.append(flt.submit(frames[f], parity[f]))
+        while inflight:
+            got.append(flt.collect(inflight.pop(0)))
+        assert flt.info().banded_frames == n
+        for f in range(n):
+            for p in range(clip.planes):
+                assert same(want[f][p], got[f][p]), f"ring frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
