@@ -605,8 +605,14 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             if (wave > 0) t_lo = t_hi = (wave - 1) * 64 + (64 - 2 * GH) + lane;
             else { t_hi = (NW - 1) * 64 + (64 - 2 * GH) + lane; c_hi = 0; }  // hi half <- strip NW-1 (a low half)
         } else if (lane >= 64 - GH) {
-            if (wave < NW - 1) t_lo = t_hi = (wave + 1) * 64 + GH + (lane - (64 - GH));
-            else { t_lo = GH + (lane - (64 - GH)); c_lo = 1; }               // lo half <- strip NW (a high half)
+            // only where these lanes ARE ghosts: in the last strip they own columns (lanes 62, 63 of a strip that ends
+            // there -- 64 + 60 k lanes, e.g. 512 or 992 columns -- read their own chunks; treating them as ghosts made
+            // the sweep see zeros in the last 16 columns of the previous pass's rows)
+            if (ghost[0]) {
+                if (wave < NW - 1) t_lo = (wave + 1) * 64 + GH + (lane - (64 - GH));
+                else { t_lo = GH + (lane - (64 - GH)); c_lo = 1; }           // lo half <- strip NW (a high half)
+            }
+            if (ghost[1]) t_hi = (wave + 1) * 64 + GH + (lane - (64 - GH));  // strip wave + NW + 1: the next wave's high half
         }
         // a pool row is [chunk kind][thread][8 bytes]: the chunks of one kind lie side by side, so the lanes inside the
         // cone write and read whole cache lines (interleaved with the other kind every line was half useful)

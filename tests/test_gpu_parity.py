@@ -206,7 +206,9 @@ FUSED_CASES = [
     ("YUV420P8", 1024, 40, dict(aac=48)),          # chroma region ends inside a strip
     ("YUV420P8", 1984, 24, dict(aac=48, order=0)),
     ("YUV420P8", 3840, 48, dict(aac=48)),
-    ("YUV420P8", 96, 8, dict(aac=48)),             # a single interpolated chroma row
+    ("YUV420P8", 96, 8, dict(aac=48)),
+    ("YUV422P8", 512, 240, dict(dh=True, aa=128, aac=128)),   # found by tools/fuzz.py: the last 16 columns of a 512-wide pool
+    ("YUV420P8", 512, 400, dict(aa=128, aac=128)),             # a single interpolated chroma row
     ("YUV420P8", 96, 4, dict(aac=48)),             # chroma planes too short to interpolate
     ("YUV422P8", 576, 28, dict(aac=48)),           # chroma as tall as luma
     ("YUV420P8", 320, 20, dict(dh=True, aac=48)),
@@ -363,7 +365,10 @@ def test_full_size_16bit_and_float_match_oracle(hip_lib, fmt, w, h, kw):
 
 COUPLED = [("YUV420P8", 256, 64), ("YUV420P8", 1920, 1080), ("YUV420P8", 3840, 2160), ("YUV420P8", 7680, 360),
            ("YUV420P10", 1920, 1080), ("YUV420P16", 640, 48), ("YUV420P16", 3840, 2160),
-           ("YUV420PS", 640, 48), ("YUV420PS", 1920, 1080), ("YUV420PS", 3840, 2160)]
+           ("YUV420PS", 640, 48), ("YUV420PS", 1920, 1080), ("YUV420PS", 3840, 2160),
+           # 64 + 60 k lanes: lanes 62, 63 of the last strip own columns (they are ghosts everywhere else), and the frame is
+           # tall enough for the dependency cone to reach them
+           ("YUV420P8", 512, 640), ("YUV420P8", 992, 720), ("YUV420P16", 512, 640), ("YUV420PS", 512, 640)]
 
 
 @pytest.mark.parametrize("fmt,w,h", COUPLED, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in COUPLED])

@@ -32,7 +32,7 @@ def main():
     rng = random.Random(a.seed)
     t_end = time.time() + a.seconds
     n = bad = 0
-    stats = {"fused": 0, "pool": 0, "ring": 0, "host": 0, "frames": 0, "pixels": 0}
+    stats = {"fused": 0, "pool": 0, "ring": 0, "host": 0, "frames": 0, "pixels": 0, "banded_frames": 0, "band_fallbacks": 0}
     while time.time() < t_end:
         fmt = rng.choice(FORMATS)
         wide = rng.random() < 0.15
@@ -40,6 +40,8 @@ def main():
         if rng.random() < 0.25:
             w = rng.choice([40, 72, 100, 200, 360, 720, 1080]) if not wide else 2160  # not a multiple of 32
         h = 2 * rng.randint(1, 40 if not wide else 12)
+        if rng.random() < 0.3:
+            h = 2 * rng.randint(20, 200 if not wide else 60)  # tall enough for the row bands of the latency path
         probe = clip_format(fmt, 64, 32)
         if probe.planes == 3:
             w -= w % (4 if probe.subw else 1) or 0
@@ -75,7 +77,7 @@ def main():
                     outs.append(o.process([pl], parity=parity[f])[0])
                 want.append(outs)
         way = rng.choice(["host", "ring"])
-        os.environ["SN_PREFER_POOL"] = rng.choice(["0", "0", "1"])  # mostly the sweeps, sometimes auto mode's small-launch pool path
+        os.environ["SN_PREFER_POOL"] = rng.choice(["0", "1"])  # the whole-plane sweeps, or auto mode's small-launch paths (bands, pool kernels)
         try:
             flt = SangNom2(clip, host_depth=rng.randint(1, 5), isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", **kw)
         except Exception as e:  # a geometry the library rejects must be one it documents
@@ -83,6 +85,10 @@ def main():
                 continue
             raise
         with flt:
+            band_set = None
+            if os.environ["SN_PREFER_POOL"] == "1":  # auto mode: the row bands too, now and then with a run-up that is too short
+                band_set = (rng.choice([0, 0, 2, 3, 5, 9, 16]), rng.choice([0, 0, 0, 1, 6, 12]))
+                flt.set_bands(*band_set)
             got = []
             fused = False
             stats[way] += 1
@@ -99,13 +105,21 @@ def main():
                     inflight.append(flt.submit(frames[f], parity=parity[f]))
                 while inflight:
                     got.append(flt.collect(inflight.pop(0)))
-            fused = flt.info().fused_frames > 0
+            info = flt.info()
+            fused = info.fused_frames > 0
+            stats["banded_frames"] += info.banded_frames
+            stats["band_fallbacks"] += info.band_fallbacks
         stats["fused" if fused else "pool"] += 1
         for f in range(nframes):
             for p in range(clip.planes):
                 if not same(want[f][p], got[f][p]):
                     bad += 1
-                    print(f"MISMATCH {fmt} {w}x{h} {kw} ext={ext} way={way} frame {f} plane {p}", flush=True)
+                    d = np.argwhere(want[f][p] != got[f][p])
+                    np.savez(f"gpurun_out/fuzz_mismatch_{n}.npz", **{f"src{q}": frames[f][q] for q in range(clip.planes)},
+                             **{f"want{q}": want[f][q] for q in range(clip.planes)}, **{f"got{q}": got[f][q] for q in range(clip.planes)})
+                    print(f"MISMATCH {fmt} {w}x{h} {kw} ext={ext} way={way} frame {f}/{nframes} plane {p} pattern={pattern} parity={parity} "
+                          f"prefer_pool={os.environ['SN_PREFER_POOL']} bands={band_set} banded={info.banded_frames} fallbacks={info.band_fallbacks} "
+                          f"fused={info.fused_frames} n={len(d)} rows {d[:, 0].min()}..{d[:, 0].max()} cols {d[:, 1].min()}..{d[:, 1].max()}", flush=True)
         n += 1
         if n % 50 == 0:
             print(f"{n} configurations, {bad} mismatches", flush=True)
