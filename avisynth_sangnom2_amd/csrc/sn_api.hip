@@ -1226,6 +1226,7 @@ int sn_unpin_host_buffer(void* ptr)
             }
         if (!found) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "sn_unpin_host_buffer: not pinned through sn_pin_host_buffer");
     }
+    (void)hipDeviceSynchronize();  // nothing of this process may still be moving data through the mapping
     const hipError_t e = hipHostUnregister(ptr);
     if (e != hipSuccess) return sn::fail(nullptr, SN_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
     return SN_OK;
