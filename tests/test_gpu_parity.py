@@ -1058,6 +1058,25 @@ def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, 
                 assert same(want[f][p], got[f][p]), f"ring frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
 
 
+@pytest.mark.parametrize("fmt", ["YUV420P8", "YUV422P8", "YUV420P16", "YUV420PS"])
+@pytest.mark.parametrize("w,h", [(512, 400), (992, 720), (1472, 1000), (544, 400), (1024, 720)])
+def test_coupled_sweeps_equal_the_pool_path_where_the_cone_reaches_the_last_columns(hip_lib, fmt, w, h):
+    """Tall frames of widths whose last strip ends on lanes 62 / 63 (64 + 60 k lanes: 512, 992, 1472) and of their
+    neighbours: the hand-off's dependency cone then includes the last columns of the pool, which short test frames
+    never reach (the 8-bit sweeps once read zeros there).  Whole-plane sweeps against the pool path, byte for byte."""
+    hh = h if fmt != "YUV422P8" else h // 2
+    clip = clip_format(fmt, w, hh)
+    kw = dict(aa=128, aac=128)
+    for pattern in ("edges", "noise"):
+        src = synth.frame(clip, pattern, seed=5)
+        outs = {}
+        for mode in ("fused", "pool"):
+            with SangNom2(clip, mode=mode, **kw) as flt:
+                outs[mode] = flt.get_frame(src)
+        for p in range(3):
+            assert same(outs["pool"][p], outs["fused"][p]), f"{pattern} plane {p}: " + describe_diff(outs["pool"][p], outs["fused"][p])
+
+
 # ---- last in the file on purpose: hipHostRegister / hipHostUnregister on the test's own arrays.  With this test in the
 # middle of the suite, later tests that hand pageable numpy arrays to the synchronous entry point were hit, once in a
 # few runs, by a GPU page fault reported from the HSA runtime's event thread (three times in test_row_bands_match_oracle,
