@@ -320,6 +320,22 @@ def main():
                          "kernel_ms_per_launch": round(launch_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu},
         }
+        if world == 1 and not args.no_cpu_baseline:  # (the profiling passes run with --no-cpu-baseline: the hot path only)
+            # the other end of the scale: ONE frame per launch (what a synchronous GetFrame sees), device time per frame;
+            # auto mode cuts such a launch into row bands where the planes allow it
+            one_s, one_d = [t[:1] for t in src], [t[:1] for t in dst]
+            with SangNom2(clip, device=dev_index, max_batch=1, stream=stream.cuda_stream, **kw) as lat:
+                for _ in range(5):
+                    lat.process_batch(one_s, one_d)
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record(stream)
+                for _ in range(50):
+                    lat.process_batch(one_s, one_d)
+                a1.record(stream)
+                torch.cuda.synchronize(dev)
+                li = lat.info()
+                out["single_frame"] = {"ms": round(a0.elapsed_time(a1) / 50, 4), "banded": li.banded_frames > 0,
+                                       "band_fallbacks": int(li.band_fallbacks), "launches": 50}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fmt, w, h, kw)
         print(json.dumps(out), flush=True)
