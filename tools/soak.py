@@ -24,6 +24,9 @@ CASES = [
     ("YUV420P8", 720, 480, dict(aa=48, aac=48, fresh_pool=True), 96),
     ("Y8", 2160, 3840, dict(aa=48, fresh_pool=True), 24),
     ("YUV420P8", 1920, 1080, dict(aa=48, aac=48, isolated_planes=True), 32),
+    ("YUV420PS", 3840, 2160, dict(aa=48, aac=48), 6),
+    ("YUV420P8", 512, 1024, dict(aa=128, aac=128), 64),    # 64 lanes: lanes 62 / 63 of the only strip own columns
+    ("YUV422P8", 992, 540, dict(aa=128, aac=128), 48),     # 124 lanes: the same in the second strip
 ]
 
 
