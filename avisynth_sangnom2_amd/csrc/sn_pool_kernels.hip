@@ -283,6 +283,80 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, i
     }
 }
 
+// 9..16-bit pools: eight columns per thread as well, one 32-bit sum per register (seven 3-row sums of 16-bit samples need 21
+// bits), a sliding box (two instructions per further column instead of three three-operand adds), one 16-byte row
+// access and two 16-byte LDS reads per thread and row: 55 vector instructions per 8 columns against 79 per 4.
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, int slot0)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;  // a multiple of 32
+    const int nt = se >> 3;        // threads that own columns
+    uint4* line0 = reinterpret_cast<uint4*>(smem);  // [thread][2]: sums of its columns 0..3 and 4..7
+    uint4* line1 = line0 + 2 * nt;
+    const int b = blockIdx.x;
+    const int f = blockIdx.y;
+    if (pool.guard && pool.guard[f] == 0) return;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    const int tid = threadIdx.x;
+    const bool active = tid < nt;
+    const int t = active ? tid : 0;  // idle lanes of the last wave shadow thread 0 and store nothing
+    const bool first = t == 0, last = t == nt - 1;
+    const int tl = first ? 0 : t - 1, tr = last ? t : t + 1;
+
+    struct Row {
+        unsigned v[8];
+    };
+    auto unpack = [](uint4 q) {
+        Row r;
+        r.v[0] = q.x & 0xffffu; r.v[1] = q.x >> 16;
+        r.v[2] = q.y & 0xffffu; r.v[3] = q.y >> 16;
+        r.v[4] = q.z & 0xffffu; r.v[5] = q.z >> 16;
+        r.v[6] = q.w & 0xffffu; r.v[7] = q.w >> 16;
+        return r;
+    };
+    auto load = [&](int row) { return *reinterpret_cast<const uint4*>(buf + (size_t)row * se + 8 * t); };
+    auto row_or_last = [&](int row) { return row <= pool.bh ? row : pool.bh; };  // past the end: loaded, never used
+    Row prev = unpack(load(0)), cur = unpack(load(1)), nxt = unpack(load(row_or_last(2)));
+    const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    for (int r = 1; r < rows; ++r) {
+        const uint4 pre = load(row_or_last(r + 2));  // fetched one row step ahead of its first use
+        uint4* line = (r & 1) ? line1 : line0;
+        unsigned X[14];  // sums of columns 8t - 3 .. 8t + 10
+#pragma unroll
+        for (int i = 0; i < 8; ++i) X[3 + i] = prev.v[i] + cur.v[i] + nxt.v[i];
+        if (active) {
+            line[2 * t] = make_uint4(X[3], X[4], X[5], X[6]);
+            line[2 * t + 1] = make_uint4(X[7], X[8], X[9], X[10]);
+        }
+        __syncthreads();
+        const uint4 lf = line[2 * tl + 1], rt = line[2 * tr];
+        // the pool row is clamped at both ends (SangNom2.cpp:144-150)
+        X[0] = first ? X[3] : lf.y;
+        X[1] = first ? X[3] : lf.z;
+        X[2] = first ? X[3] : lf.w;
+        X[11] = last ? X[10] : rt.x;
+        X[12] = last ? X[10] : rt.y;
+        X[13] = last ? X[10] : rt.z;
+        unsigned T = ((X[0] + X[1]) + X[2]) + ((X[3] + X[4]) + (X[5] + X[6]));
+        Row o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o.v[k] = (T >> 4) & 0xffffu;  // (sum / 16) wraps to uint16_t, SangNom2.cpp:152; integer sums: any order
+            if (k < 7) T = (T - X[k]) + X[k + 7];
+        }
+        uint4 q;
+        q.x = o.v[0] | (o.v[1] << 16);
+        q.y = o.v[2] | (o.v[3] << 16);
+        q.z = o.v[4] | (o.v[5] << 16);
+        q.w = o.v[6] | (o.v[7] << 16);
+        if (active) *reinterpret_cast<uint4*>(buf + (size_t)r * se + 8 * t) = q;
+        prev = o;
+        cur = nxt;
+        nxt = unpack(pre);
+    }
+}
+
 // Pools narrower than 1024 columns: one column per thread, columns strided by the workgroup size.  (Measured on
 // 720-wide clips: 12 % faster per row than the NC = 1 instance of the kernel above, which wins from 1024 columns on.)
 template <class T, int NC>
@@ -406,6 +480,13 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
         const int threads = ((pool.stride_e / 8) + 63) / 64 * 64;
         const size_t lds = (size_t)2 * (pool.stride_e / 8) * sizeof(uint4);
         hipLaunchKernelGGL(k_smooth_u8x2, dim3(kBuffers, nframes), dim3(threads), lds, st, pool, slot0);
+    } else if (std::is_same<T, uint16_t>::value && pool.bh > 1 && pool.stride_e >= 256 && pool.stride_e <= 8 * kSmoothThreads) {
+        const int threads = ((pool.stride_e / 8) + 63) / 64 * 64;
+        const size_t lds = (size_t)2 * 2 * (pool.stride_e / 8) * sizeof(uint4);
+        hipError_t e = hipSuccess;
+        if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)k_smooth_u16x8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_smooth_u16x8, dim3(kBuffers, nframes), dim3(threads), lds, st, pool, slot0);
     } else if (pool.bh > 1) {
         // columns per thread: what 1024 threads need, and 4 for every pool of 1024 columns or more (vector accesses,
         // fewer LDS round trips); narrower pools do best with one column per thread
