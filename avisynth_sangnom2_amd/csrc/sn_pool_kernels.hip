@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
 // each (a 7-tap sum of 3-row sums stays below 5 355, so plain 32-bit adds never carry from one half into the other);
 // the odd-aligned pairs the box needs come from v_alignbit, the box slides (two instructions per further pair), the
 // neighbours' sums arrive as two 8-byte LDS reads instead of six 4-byte ones.  45 vector instructions per 8 columns and
-// row against 79 per 4: stage 2 of one 2160p pool 830 -> about 280 us.
+// row against 79 per 4: stage 2 of one 2160p pool 830 -> 454 us.
 __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, int slot0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -285,7 +285,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, i
 
 // 9..16-bit pools: eight columns per thread as well, one 32-bit sum per register (seven 3-row sums of 16-bit samples need 21
 // bits), a sliding box (two instructions per further column instead of three three-operand adds), one 16-byte row
-// access and two 16-byte LDS reads per thread and row: 55 vector instructions per 8 columns against 79 per 4.
+// access and two 16-byte LDS reads per thread and row: 55 vector instructions per 8 columns against 79 per 4
+// (one 2160p pool 830 -> 613 us).
 __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, int slot0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
