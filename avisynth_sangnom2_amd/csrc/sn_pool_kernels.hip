@@ -244,8 +244,13 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, i
     auto row_or_last = [&](int row) { return row <= pool.bh ? row : pool.bh; };  // past the end: loaded, never used
     Row prev = unpack(load(0)), cur = unpack(load(1)), nxt = unpack(load(row_or_last(2)));
     const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
-    for (int r = 1; r < rows; ++r) {
-        const uint2 pre = load(row_or_last(r + 2));  // fetched one row step ahead of its first use
+    // rows r + 2 .. r + 1 + kAhead are in flight: with two waves per SIMD a row step is too short to cover the latency of
+    // a pool row that comes from HBM or a far L2; the ring is indexed by the unrolled position only
+    constexpr int kAhead = 4;
+    uint2 ring[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) ring[u] = load(row_or_last(3 + u));
+    auto row_step = [&](int r, uint2 pre) {  // pre = row r + 2
         uint4* line = (r & 1) ? line1 : line0;
         // E[2 + j] = sums of columns 8t + 2j | 8t + 2j + 1, j = -2 .. 5
         unsigned E[8];
@@ -280,6 +285,16 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, i
         prev = o;
         cur = nxt;
         nxt = unpack(pre);
+    };
+    for (int r = 1; r < rows; r += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (r + u < rows) {  // uniform
+                const uint2 pre = ring[u];
+                ring[u] = load(row_or_last(r + u + 2 + kAhead));
+                row_step(r + u, pre);
+            }
+        }
     }
 }
 
@@ -320,8 +335,11 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, 
     auto row_or_last = [&](int row) { return row <= pool.bh ? row : pool.bh; };  // past the end: loaded, never used
     Row prev = unpack(load(0)), cur = unpack(load(1)), nxt = unpack(load(row_or_last(2)));
     const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
-    for (int r = 1; r < rows; ++r) {
-        const uint4 pre = load(row_or_last(r + 2));  // fetched one row step ahead of its first use
+    constexpr int kAhead = 4;  // rows in flight, as in k_smooth_u8x2
+    uint4 ring[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) ring[u] = load(row_or_last(3 + u));
+    auto row_step = [&](int r, uint4 pre) {  // pre = row r + 2
         uint4* line = (r & 1) ? line1 : line0;
         unsigned X[14];  // sums of columns 8t - 3 .. 8t + 10
 #pragma unroll
@@ -355,6 +373,16 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, 
         prev = o;
         cur = nxt;
         nxt = unpack(pre);
+    };
+    for (int r = 1; r < rows; r += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (r + u < rows) {  // uniform
+                const uint4 pre = ring[u];
+                ring[u] = load(row_or_last(r + u + 2 + kAhead));
+                row_step(r + u, pre);
+            }
+        }
     }
 }
 
