@@ -560,6 +560,12 @@ static int band_count(Context* c, int n, int slot0)
     for (int p = 0; p < c->nplanes(); ++p)
         if (c->cfg.dh || c->process[p]) nr_min = c->plane_h_out(p) / 2 - 1 < nr_min ? c->plane_h_out(p) / 2 - 1 : nr_min;
     if (nr_min == (1 << 30) || nr_min < 2 * kMinBandRows) return 0;
+    int nb = c->band_force > 0 ? c->band_force : 512 / n;  // about two workgroups per CU in all
+    if (nb > nr_min / kMinBandRows) nb = nr_min / kMinBandRows;
+    if (nb > kMaxBands) nb = kMaxBands;
+    if (nb < (c->band_force > 0 ? 2 : 3)) return 0;  // a launch of hundreds of frames fills the device with whole-plane sweeps
+    if (c->band_force == 0 && nr_min / nb < band_warm_rows(c) / 4) nb = nr_min / (band_warm_rows(c) / 4);  // run-up <= 4 x own rows
+    if (nb < 2) return 0;
     if (c->band_force == 0 && c->band_fallbacks) {
         const int64_t seen = *c->band_fallbacks;  // as of the last banded launch that has finished
         if (seen != c->band_fallbacks_seen) {
@@ -575,11 +581,7 @@ static int band_count(Context* c, int n, int slot0)
             return 0;
         }
     }
-    int nb = c->band_force > 0 ? c->band_force : 512 / n;  // about two workgroups per CU in all
-    if (nb > nr_min / kMinBandRows) nb = nr_min / kMinBandRows;
-    if (nb > kMaxBands) nb = kMaxBands;
-    if (c->band_force == 0 && nr_min / nb < band_warm_rows(c) / 4) nb = nr_min / (band_warm_rows(c) / 4);  // run-up <= 4 x own rows
-    return nb >= 2 ? nb : 0;
+    return nb;
 }
 
 // The band fields of one sweep over pool rows 1 .. last, at most `want` bands.
