@@ -542,8 +542,10 @@ static int band_warm_rows(const Context* c)
     return c->cfg.bytes_per_sample == 1 ? 32 : c->cfg.bytes_per_sample == 2 ? 40 : 48;
 }
 
-// Bands per frame for a launch of n frames on slots slot0.., 0 = do not cut.
-static int band_count(Context* c, int n, int slot0)
+constexpr int kMaxBandSlots = 192;  // launches of more frames than that fill the device without bands
+
+// Rows of the shortest processed plane if this context can cut small launches into bands at all, else 0.
+static int band_rows_available(const Context* c)
 {
     if (c->band_force < 0 || c->cfg.mode != SN_MODE_AUTO || !c->history_free) return 0;
     if (c->isolated) {  // every processed plane must have the sweep for planes on their own (not the padded one)
@@ -552,14 +554,21 @@ static int band_count(Context* c, int n, int slot0)
     } else if (!c->use_fused) {
         return 0;
     }
-    if (slot0 + n > c->slots) return 0;  // the fallback needs the frames' pool slots
-    if (c->band_force == 0)
-        if (const char* e = getenv("SN_PREFER_POOL"))  // 0: whole-plane sweeps always (see prefer_pool)
-            if (atoi(e) == 0) return 0;
     int nr_min = 1 << 30;
     for (int p = 0; p < c->nplanes(); ++p)
         if (c->cfg.dh || c->process[p]) nr_min = c->plane_h_out(p) / 2 - 1 < nr_min ? c->plane_h_out(p) / 2 - 1 : nr_min;
-    if (nr_min == (1 << 30) || nr_min < 2 * kMinBandRows) return 0;
+    return nr_min == (1 << 30) || nr_min < 2 * kMinBandRows ? 0 : nr_min;
+}
+
+// Bands per frame for a launch of n frames on slots slot0.., 0 = do not cut.
+static int band_count(Context* c, int n, int slot0)
+{
+    const int nr_min = band_rows_available(c);
+    if (nr_min == 0) return 0;
+    if (slot0 + n > c->slots || slot0 + n > kMaxBandSlots) return 0;  // the fallback needs the frames' pool slots
+    if (c->band_force == 0)
+        if (const char* e = getenv("SN_PREFER_POOL"))  // 0: whole-plane sweeps always (see prefer_pool)
+            if (atoi(e) == 0) return 0;
     int nb = c->band_force > 0 ? c->band_force : 512 / n;  // about two workgroups per CU in all
     if (nb > nr_min / kMinBandRows) nb = nr_min / kMinBandRows;
     if (nb > kMaxBands) nb = kMaxBands;
@@ -611,8 +620,9 @@ static int ensure_bands(Context* c)
 {
     if (c->band_state) return SN_OK;
     c->band_words = sn::band_state_words(band_threads(c), kMaxBands);
-    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_state), (size_t)c->band_words * 4 * c->slots));
-    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_flags), sizeof(int32_t) * c->slots));
+    const int slots = c->slots < kMaxBandSlots ? c->slots : kMaxBandSlots;
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_state), (size_t)c->band_words * 4 * slots));
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_flags), sizeof(int32_t) * slots));
     SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_fallbacks_dev), sizeof(int64_t)));
     SN_HIP(c, hipMemsetAsync(c->band_fallbacks_dev, 0, sizeof(int64_t), c->stream));
     SN_HIP(c, hipStreamSynchronize(c->stream));
@@ -636,7 +646,7 @@ static int prepare_small_launch_scratch(Context* c)
     } else if (c->use_fused) {
         rc = ensure_pool(c);
     }
-    if (rc == SN_OK && c->band_force >= 0 && (c->isolated || c->use_fused)) rc = ensure_bands(c);
+    if (rc == SN_OK && band_rows_available(c) > 0) rc = ensure_bands(c);
     return rc;
 }
 

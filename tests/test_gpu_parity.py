@@ -1058,6 +1058,31 @@ def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, 
                 assert same(want[f][p], got[f][p]), f"ring frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
 
 
+def test_launches_of_hundreds_of_small_frames_stay_on_the_whole_plane_sweeps(hip_lib, monkeypatch):
+    """More than 512 frames in one launch of an isolated-planes context (which has a scratch slot for each of them): the band
+    count works out as zero there -- once a division by it -- and the launch must take the whole-plane sweeps."""
+    import torch
+    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
+    clip = clip_format("YUV420P8", 128, 80)
+    N = 600
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    src = [torch.randint(0, 256, (N, 80 >> (1 if p else 0), 128 >> (1 if p else 0)), device=dev, generator=g, dtype=torch.uint8) for p in range(3)]
+    outs = {}
+    for mode in ("auto", "fused"):
+        with SangNom2(clip, max_batch=N, mode=mode, isolated_planes=True, aac=48) as flt:
+            dst = [torch.zeros_like(s) for s in src]
+            torch.cuda.synchronize()
+            flt.process_batch(src, dst)
+            flt.synchronize()
+            info = flt.info()
+            assert (info.fused_frames, info.banded_frames) == (N, 0)
+            outs[mode] = [d.cpu().numpy() for d in dst]
+    for p in range(3):
+        assert np.array_equal(outs["auto"][p], outs["fused"][p])
+
+
 @pytest.mark.parametrize("fmt", ["YUV420P8", "YUV422P8", "YUV420P16", "YUV420PS"])
 @pytest.mark.parametrize("w,h", [(512, 400), (992, 720), (1472, 1000), (544, 400), (1024, 720)])
 def test_coupled_sweeps_equal_the_pool_path_where_the_cone_reaches_the_last_columns(hip_lib, fmt, w, h):
