@@ -36,12 +36,14 @@ def main():
     while time.time() < t_end:
         fmt = rng.choice(FORMATS)
         wide = rng.random() < 0.15
-        w = rng.choice([32, 64, 96, 128, 160, 256, 320, 512, 544, 640, 1024]) if not wide else rng.choice([1920, 2048, 2880, 3840, 4096, 5120, 7680])
+        w = rng.choice([32, 64, 96, 128, 160, 256, 320, 512, 544, 640, 992, 1024]) if not wide else rng.choice([1472, 1920, 1952, 2048, 2432, 2880, 3840, 4096, 5120, 7680])
         if rng.random() < 0.25:
             w = rng.choice([40, 72, 100, 200, 360, 720, 1080]) if not wide else 2160  # not a multiple of 32
         h = 2 * rng.randint(1, 40 if not wide else 12)
         if rng.random() < 0.3:
             h = 2 * rng.randint(20, 200 if not wide else 60)  # tall enough for the row bands of the latency path
+            if rng.random() < 0.15:
+                h = 2 * rng.randint(200, 540)  # ... and for the hand-off's dependency cone to reach the last columns
         probe = clip_format(fmt, 64, 32)
         if probe.planes == 3:
             w -= w % (4 if probe.subw else 1) or 0
