@@ -1058,6 +1058,43 @@ def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, 
                 assert same(want[f][p], got[f][p]), f"ring frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
 
 
+@pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 512, 300, {}), ("YUV420P8", 256, 320, dict(aac=48)), ("Y16", 256, 240, {})])
+def test_filter_instances_on_their_own_threads(hip_lib, monkeypatch, fmt, w, h, kw):
+    """MT_MULTI_INSTANCE (SangNom2.h:63-66): the host runs several instances of the filter at once, each on its own thread
+    with its own context.  Four threads, each with a context of its own, call the synchronous entry point on their own
+    frames (the latency path: bands, checks, guarded pool kernels, each context on its own stream and scratch)."""
+    import threading
+    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
+    clip = clip_format(fmt, w, h)
+    T, N = 4, 6
+    frames = [[synth.frame(clip, "noise" if (t + f) % 3 else "checker", seed=100 * t + f) for f in range(N)] for t in range(T)]
+    want = []
+    for t in range(T):
+        ora = Oracle(oracle_cfg(clip, **kw))
+        want.append([ora.process(frames[t][f], parity=f & 1) for f in range(N)])
+    got = [[None] * N for _ in range(T)]
+    errors = []
+
+    def work(t):
+        try:
+            with SangNom2(clip, **kw) as flt:
+                for f in range(N):
+                    got[t][f] = flt.get_frame(frames[t][f], parity=f & 1)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for t in range(T):
+        for f in range(N):
+            for p in range(len(want[t][f])):
+                assert same(want[t][f][p], got[t][f][p]), f"thread {t} frame {f} plane {p}"
+
+
 def test_launches_of_hundreds_of_small_frames_stay_on_the_whole_plane_sweeps(hip_lib, monkeypatch):
     """More than 512 frames in one launch of an isolated-planes context (which has a scratch slot for each of them): the band
     count works out as zero there -- once a division by it -- and the launch must take the whole-plane sweeps."""
