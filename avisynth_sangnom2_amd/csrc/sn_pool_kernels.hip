@@ -386,6 +386,94 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, 
     }
 }
 
+// Float pools: eight columns per thread too.  The sums keep the reference's order -- (a + b) + c for the three rows, the
+// seven taps left to right (SangNom2.cpp:144-152) -- so nothing slides; what is saved is the per-thread overhead (half
+// the waves, one 32-byte row access, two 16-byte LDS reads per thread and row) and the row latency (four rows in flight).
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32x8(PoolArgs pool, int slot0)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;  // a multiple of 32
+    const int nt = se >> 3;        // threads that own columns
+    float4* line0 = reinterpret_cast<float4*>(smem);  // [thread][2]: sums of its columns 0..3 and 4..7
+    float4* line1 = line0 + 2 * nt;
+    const int b = blockIdx.x;
+    const int f = blockIdx.y;
+    if (pool.guard && pool.guard[f] == 0) return;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    float* buf = reinterpret_cast<float*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    const int tid = threadIdx.x;
+    const bool active = tid < nt;
+    const int t = active ? tid : 0;  // idle lanes of the last wave shadow thread 0 and store nothing
+    const bool first = t == 0, last = t == nt - 1;
+    const int tl = first ? 0 : t - 1, tr = last ? t : t + 1;
+
+    struct Row {
+        float4 lo, hi;
+        __device__ __forceinline__ float at(int i) const
+        {
+            return i == 0 ? lo.x : i == 1 ? lo.y : i == 2 ? lo.z : i == 3 ? lo.w : i == 4 ? hi.x : i == 5 ? hi.y : i == 6 ? hi.z : hi.w;
+        }
+    };
+    auto load = [&](int row) {
+        const float4* p = reinterpret_cast<const float4*>(buf + (size_t)row * se + 8 * t);
+        Row r;
+        r.lo = p[0];
+        r.hi = p[1];
+        return r;
+    };
+    auto row_or_last = [&](int row) { return row <= pool.bh ? row : pool.bh; };  // past the end: loaded, never used
+    Row prev = load(0), cur = load(1), nxt = load(row_or_last(2));
+    const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    constexpr int kAhead = 4;  // rows in flight, as in k_smooth_u8x2
+    Row ring[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) ring[u] = load(row_or_last(3 + u));
+    auto row_step = [&](int r, const Row& pre) {  // pre = row r + 2
+        float4* line = (r & 1) ? line1 : line0;
+        float X[14];  // sums of columns 8t - 3 .. 8t + 10
+#pragma unroll
+        for (int i = 0; i < 8; ++i) X[3 + i] = (prev.at(i) + cur.at(i)) + nxt.at(i);
+        if (active) {
+            line[2 * t] = make_float4(X[3], X[4], X[5], X[6]);
+            line[2 * t + 1] = make_float4(X[7], X[8], X[9], X[10]);
+        }
+        __syncthreads();
+        const float4 lf = line[2 * tl + 1], rt = line[2 * tr];
+        // the pool row is clamped at both ends (SangNom2.cpp:144-150)
+        X[0] = first ? X[3] : lf.y;
+        X[1] = first ? X[3] : lf.z;
+        X[2] = first ? X[3] : lf.w;
+        X[11] = last ? X[10] : rt.x;
+        X[12] = last ? X[10] : rt.y;
+        X[13] = last ? X[10] : rt.z;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)  // left to right, SangNom2.cpp:152
+            o[k] = ((((((X[k] + X[k + 1]) + X[k + 2]) + X[k + 3]) + X[k + 4]) + X[k + 5]) + X[k + 6]) * 0.0625f;
+        Row out;
+        out.lo = make_float4(o[0], o[1], o[2], o[3]);
+        out.hi = make_float4(o[4], o[5], o[6], o[7]);
+        if (active) {
+            float4* q = reinterpret_cast<float4*>(buf + (size_t)r * se + 8 * t);
+            q[0] = out.lo;
+            q[1] = out.hi;
+        }
+        prev = out;
+        cur = nxt;
+        nxt = pre;
+    };
+    for (int r = 1; r < rows; r += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (r + u < rows) {  // uniform
+                const Row pre = ring[u];
+                ring[u] = load(row_or_last(r + u + 2 + kAhead));
+                row_step(r + u, pre);
+            }
+        }
+    }
+}
+
 // Pools narrower than 1024 columns: one column per thread, columns strided by the workgroup size.  (Measured on
 // 720-wide clips: 12 % faster per row than the NC = 1 instance of the kernel above, which wins from 1024 columns on.)
 template <class T, int NC>
@@ -516,6 +604,13 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
         if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)k_smooth_u16x8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_smooth_u16x8, dim3(kBuffers, nframes), dim3(threads), lds, st, pool, slot0);
+    } else if (std::is_same<T, float>::value && pool.bh > 1 && pool.stride_e >= 256 && pool.stride_e <= 8 * kSmoothThreads) {
+        const int threads = ((pool.stride_e / 8) + 63) / 64 * 64;
+        const size_t lds = (size_t)2 * 2 * (pool.stride_e / 8) * sizeof(float4);
+        hipError_t e = hipSuccess;
+        if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)k_smooth_f32x8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_smooth_f32x8, dim3(kBuffers, nframes), dim3(threads), lds, st, pool, slot0);
     } else if (pool.bh > 1) {
         // columns per thread: what 1024 threads need, and 4 for every pool of 1024 columns or more (vector accesses,
         // fewer LDS round trips); narrower pools do best with one column per thread
