@@ -84,6 +84,15 @@ struct Context {
     int ring_last = -1;       // group of the latest launch (its `swept` event is what the next launch waits for)
     int ring_pitch_in[3] = {0, 0, 0}, ring_pitch_out[3] = {0, 0, 0};
 
+    // sn_process_host pipelines its planes: copies in on one stream, out on another, the kernels of plane p between
+    // the arrival of plane p and its way back (PlaneGate); run_group waits / records per plane where it can
+    struct PlaneGate {
+        hipStream_t in = nullptr, out = nullptr;
+        hipEvent_t arrived[3] = {nullptr, nullptr, nullptr}, done[3] = {nullptr, nullptr, nullptr};
+        bool waited[3] = {false, false, false}, recorded[3] = {false, false, false};
+        bool on = false;
+    } gate;
+
     // staging for sn_process_host
     uint8_t* stage_src[3] = {nullptr, nullptr, nullptr};
     uint8_t* stage_dst[3] = {nullptr, nullptr, nullptr};
@@ -283,6 +292,14 @@ void sn_destroy(sn_context* h)
         if (c->plane_pool[p].base) (void)hipFree(c->plane_pool[p].base);
     for (int i = 0; i < 2; ++i)
         if (c->fpool[i]) (void)hipFree(c->fpool[i]);
+    if (c->gate.in) (void)hipStreamSynchronize(c->gate.in);
+    if (c->gate.out) (void)hipStreamSynchronize(c->gate.out);
+    for (int p = 0; p < 3; ++p) {
+        if (c->gate.arrived[p]) (void)hipEventDestroy(c->gate.arrived[p]);
+        if (c->gate.done[p]) (void)hipEventDestroy(c->gate.done[p]);
+    }
+    if (c->gate.in) (void)hipStreamDestroy(c->gate.in);
+    if (c->gate.out) (void)hipStreamDestroy(c->gate.out);
     if (c->band_state) (void)hipFree(c->band_state);
     if (c->band_flags) (void)hipFree(c->band_flags);
     if (c->band_fallbacks) (void)hipHostFree(c->band_fallbacks);
@@ -680,6 +697,20 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     const int nbands = all_fused ? band_count(c, n, slot0) : 0;
     if (nbands == 0 && prefer_pool(c, n, slot0))
         for (int p = 0; p < 3; ++p) fused[p] = false;
+    // sn_process_host's plane pipeline: a plane's kernels wait for its copy and announce their end; the paths that are
+    // not written plane by plane wait for everything first (the caller records what was not announced)
+    auto plane_in = [&](int p) -> hipError_t {
+        if (!c->gate.on || c->gate.waited[p]) return hipSuccess;
+        c->gate.waited[p] = true;
+        return hipStreamWaitEvent(st, c->gate.arrived[p], 0);
+    };
+    auto plane_out = [&](int p) -> hipError_t {
+        if (!c->gate.on) return hipSuccess;
+        c->gate.recorded[p] = true;
+        return hipEventRecord(c->gate.done[p], st);
+    };
+    if (nbands == 0)
+        for (int p = 0; p < c->nplanes(); ++p) SN_HIP(c, plane_in(p));
     // The reference smooths the whole luma-sized pool in every pass (SangNom2.cpp:126-159).  A plane of fewer lines reads
     // back only rows 1 .. nr of it, and a later pass of this frame reads one row further than it smooths -- when nothing
     // is carried into the next frame, rows beyond that are never looked at again and stage 2 of the pool path stops
@@ -729,8 +760,10 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         int rc = ensure_bands(c);
         if (rc != SN_OK) return rc;
         for (int p = 0; p < c->nplanes(); ++p) {
+            SN_HIP(c, plane_in(p));
             if (!pa[p].enabled) {
                 SN_HIP(c, sn::launch_assemble(st, pa[p], c->cfg.bytes_per_sample, n));
+                SN_HIP(c, plane_out(p));
                 continue;
             }
             rc = ensure_pool(c, p);
@@ -739,6 +772,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
             if (c->fresh) SN_HIP(c, hipMemsetAsync(pool.base + (int64_t)slot0 * pool.slot_bytes, 0, (size_t)pool.slot_bytes * n, st));
             rc = banded_plane(p, pa[p], pool);
             if (rc != SN_OK) return rc;
+            SN_HIP(c, plane_out(p));
         }
         SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         c->fused_frames += n;
@@ -804,6 +838,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         fp.rows_out = stop[1] < c->bh - 1 ? stop[1] : c->bh - 1;  // what U's stage 2 reads: rows up to the one it stops at
         fp.cone_nr = 1 << 20;  // every column is kept
         set_bands(c, fp, nbands, pa[0].h_out / 2 - 1, slot0, true);
+        SN_HIP(c, plane_in(0));
         if (B == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, pa[0], c->threshold(0), n, &fp));
         else if (B == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, pa[0], c->threshold(0), n, &fp));
         else SN_HIP(c, sn::launch_fused_u8_v3(st, pa[0], c->threshold(0), n, &fp));
@@ -816,11 +851,14 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         pool.rows = stop[0];
         SN_HIP(c, sn::launch_assemble(st, a, B, n));
         SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(0), n, slot0));
+        SN_HIP(c, plane_out(0));
         for (int p = 1; p < 3; ++p) {
             pool = c->pool;
             pool.rows = stop[p];
+            SN_HIP(c, plane_in(p));
             SN_HIP(c, sn::launch_assemble(st, pa[p], B, n));
             SN_HIP(c, sn::launch_pool_plane(st, pa[p], pool, B, c->threshold(p), n, slot0));
+            SN_HIP(c, plane_out(p));
         }
         c->banded_frames += n;
         return SN_OK;
@@ -869,12 +907,15 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         if (rc != SN_OK) return rc;
         for (int p = 0; p < c->nplanes(); ++p) {
             sn::PlaneArgs a = pa[p];
+            SN_HIP(c, plane_in(p));
             if (!a.enabled) {
                 SN_HIP(c, sn::launch_assemble(st, a, c->cfg.bytes_per_sample, n));
+                SN_HIP(c, plane_out(p));
                 continue;
             }
             rc = banded_plane(p, a, c->pool);
             if (rc != SN_OK) return rc;
+            SN_HIP(c, plane_out(p));
         }
         SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         c->fused_frames += n;
@@ -977,18 +1018,47 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
             SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_dst[p]),
                                 (size_t)c->stage_dst_pitch[p] * c->plane_h_out(p)));
         }
+    }
+    // Several planes: the copies go on streams of their own, so that plane p + 1 arrives and plane p - 1 leaves while plane
+    // p is in the kernels (a 2160p YUV420P8 call: 1.16 -> 0.9 ms).  One plane: everything in order on the context's stream.
+    Context::PlaneGate& g = c->gate;
+    const bool piped = c->nplanes() > 1;
+    if (piped && !g.in) {
+        SN_HIP(c, hipStreamCreateWithFlags(&g.in, hipStreamNonBlocking));
+        SN_HIP(c, hipStreamCreateWithFlags(&g.out, hipStreamNonBlocking));
+        for (int p = 0; p < 3; ++p) {
+            SN_HIP(c, hipEventCreateWithFlags(&g.arrived[p], hipEventDisableTiming));
+            SN_HIP(c, hipEventCreateWithFlags(&g.done[p], hipEventDisableTiming));
+        }
+    }
+    for (int p = 0; p < c->nplanes(); ++p) {
         // (a plane inside memory the caller pinned is DMA'd as it lies; a pageable one goes through the runtime's own
         // staging -- either way one call)
         SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p], c->stage_src_pitch[p], src[p], sp[p],
-                                   (size_t)c->plane_w(p) * B, c->plane_h_in(p), hipMemcpyHostToDevice, c->stream));
+                                   (size_t)c->plane_w(p) * B, c->plane_h_in(p), hipMemcpyHostToDevice, piped ? g.in : c->stream));
+        if (piped) SN_HIP(c, hipEventRecord(g.arrived[p], g.in));
     }
     const void* dsrc[3] = {c->stage_src[0], c->stage_src[1], c->stage_src[2]};
     void* ddst[3] = {c->stage_dst[0], c->stage_dst[1], c->stage_dst[2]};
+    if (piped) {
+        g.on = true;
+        for (int p = 0; p < 3; ++p) g.waited[p] = g.recorded[p] = false;
+    }
     rc = sn_process_device(h, dsrc, c->stage_src_pitch, ddst, c->stage_dst_pitch, parity);
-    if (rc != SN_OK) return rc;
-    for (int p = 0; p < c->nplanes(); ++p)
+    g.on = false;
+    if (rc != SN_OK) {
+        if (piped) (void)hipStreamSynchronize(g.in);  // nothing of this call may still be reading the caller's planes
+        return rc;
+    }
+    for (int p = 0; p < c->nplanes(); ++p) {
+        if (piped) {
+            if (!g.recorded[p]) SN_HIP(c, hipEventRecord(g.done[p], c->stream));  // a path that is not written plane by plane: all done here
+            SN_HIP(c, hipStreamWaitEvent(g.out, g.done[p], 0));
+        }
         SN_HIP(c, hipMemcpy2DAsync(dst[p], dp[p], c->stage_dst[p], c->stage_dst_pitch[p],
-                                   (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyDeviceToHost, c->stream));
+                                   (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyDeviceToHost, piped ? g.out : c->stream));
+    }
+    if (piped) SN_HIP(c, hipStreamSynchronize(g.out));
     SN_HIP(c, hipStreamSynchronize(c->stream));
     return SN_OK;
 }
