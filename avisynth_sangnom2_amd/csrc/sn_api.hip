@@ -502,6 +502,18 @@ static int field_offset(const Context* c, int parity)
     }
 }
 
+// Of a processed plane only the kept field is ever read (the other lines are the ones being interpolated,
+// SangNom2.cpp:361-366), so only those lines need to cross PCIe: line `first`, then every `step`-th, `rows` of them.  A
+// copied plane and a double-height clip (whose every line is kept) go as a whole.
+struct KeptLines {
+    int first, step, rows;
+};
+static KeptLines kept_lines(const Context* c, int p, int parity)
+{
+    if (c->cfg.dh || !c->process[p]) return {0, 1, c->plane_h_in(p)};
+    return {field_offset(c, parity), 2, c->plane_h_out(p) / 2};
+}
+
 static int check_planes(Context* c, const void* const src[3], const int32_t sp[3], void* const dst[3],
                         const int32_t dp[3])
 {
@@ -1034,8 +1046,10 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     for (int p = 0; p < c->nplanes(); ++p) {
         // (a plane inside memory the caller pinned is DMA'd as it lies; a pageable one goes through the runtime's own
         // staging -- either way one call)
-        SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p], c->stage_src_pitch[p], src[p], sp[p],
-                                   (size_t)c->plane_w(p) * B, c->plane_h_in(p), hipMemcpyHostToDevice, piped ? g.in : c->stream));
+        const KeptLines kl = kept_lines(c, p, parity);
+        SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p] + (int64_t)kl.first * c->stage_src_pitch[p], (size_t)kl.step * c->stage_src_pitch[p],
+                                   static_cast<const uint8_t*>(src[p]) + (int64_t)kl.first * sp[p], (size_t)kl.step * sp[p],
+                                   (size_t)c->plane_w(p) * B, kl.rows, hipMemcpyHostToDevice, piped ? g.in : c->stream));
         if (piped) SN_HIP(c, hipEventRecord(g.arrived[p], g.in));
     }
     const void* dsrc[3] = {c->stage_src[0], c->stage_src[1], c->stage_src[2]};
@@ -1210,19 +1224,25 @@ static int submit_impl(sn_context* h, const void* const src[3], const int32_t sp
     int njobs = 0;
     for (int p = 0; p < c->nplanes(); ++p) {
         direct_in[p] = sn::plane_is_pinned(src[p], sp[p], c->plane_w(p) * B, c->plane_h_in(p));
-        if (!direct_in[p])
-            jobs[njobs++] = {c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p], static_cast<const uint8_t*>(src[p]), c->ring_pitch_in[p], sp[p],
-                             c->plane_w(p) * B, c->plane_h_in(p)};
+        if (!direct_in[p]) {
+            const KeptLines kl = kept_lines(c, p, parity);  // only the lines that are read are staged ...
+            jobs[njobs++] = {c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p] + (int64_t)kl.first * c->ring_pitch_in[p],
+                             static_cast<const uint8_t*>(src[p]) + (int64_t)kl.first * sp[p], kl.step * c->ring_pitch_in[p], kl.step * sp[p],
+                             c->plane_w(p) * B, kl.rows};
+        }
     }
     if (njobs) c->copier->run(jobs, njobs);
     for (int p = 0; p < c->nplanes(); ++p) {
         uint8_t* dev = c->ring_dev_in[p] + (int64_t)slot * c->ring_bytes_in[p];
-        if (direct_in[p] && sp[p] == c->ring_pitch_in[p])  // same pitch on both sides: one linear transfer
-            SN_HIP(c, hipMemcpyAsync(dev, src[p], (size_t)c->ring_bytes_in[p] - (c->ring_pitch_in[p] - c->plane_w(p) * B), hipMemcpyHostToDevice, g.stream));
-        else if (direct_in[p])
-            SN_HIP(c, hipMemcpy2DAsync(dev, c->ring_pitch_in[p], src[p], sp[p], (size_t)c->plane_w(p) * B, c->plane_h_in(p), hipMemcpyHostToDevice, g.stream));
+        const KeptLines kl = kept_lines(c, p, parity);  // ... and cross PCIe
+        const uint8_t* from = direct_in[p] ? static_cast<const uint8_t*>(src[p]) : c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p];
+        const int from_pitch = direct_in[p] ? sp[p] : c->ring_pitch_in[p];
+        if (kl.step == 1 && from_pitch == c->ring_pitch_in[p])  // every line, same pitch on both sides: one linear transfer
+            SN_HIP(c, hipMemcpyAsync(dev, from, (size_t)c->ring_bytes_in[p] - (c->ring_pitch_in[p] - c->plane_w(p) * B), hipMemcpyHostToDevice, g.stream));
         else
-            SN_HIP(c, hipMemcpyAsync(dev, c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p], (size_t)c->ring_bytes_in[p], hipMemcpyHostToDevice, g.stream));
+            SN_HIP(c, hipMemcpy2DAsync(dev + (int64_t)kl.first * c->ring_pitch_in[p], (size_t)kl.step * c->ring_pitch_in[p],
+                                       from + (int64_t)kl.first * from_pitch, (size_t)kl.step * from_pitch, (size_t)c->plane_w(p) * B, kl.rows,
+                                       hipMemcpyHostToDevice, g.stream));
     }
     c->slot_state[slot] = Context::kStaged;
     c->slot_parity[slot] = parity;
