@@ -514,6 +514,39 @@ static KeptLines kept_lines(const Context* c, int p, int parity)
     return {field_offset(c, parity), 2, c->plane_h_out(p) / 2};
 }
 
+// The host's copy threads (staging of the ring, kept lines of the synchronous call): SN_COPY_THREADS in all, the caller included.
+static void ensure_copier(Context* c)
+{
+    if (c->copier) return;
+    const char* e = getenv("SN_COPY_THREADS");
+    const unsigned hw = std::thread::hardware_concurrency();
+    int workers = e ? atoi(e) - 1 : (hw >= 8 ? 3 : hw >= 4 ? 1 : 0);
+    if (workers < 0) workers = 0;
+    if (workers > 15) workers = 15;
+    c->copier = new Copier(workers);
+}
+
+// The other half of the same observation: the kept lines of the OUTPUT are copies of source lines (field copy, border
+// line, SangNom2.cpp:361-391), and a plane that is not processed is a copy altogether.  Where the caller's source is
+// still at hand (the synchronous call) the host copies those lines itself, while the device is busy, and only the
+// interpolated lines come back over PCIe.
+static int kept_line_jobs(const Context* c, int p, int parity, const void* src, int sp, void* dst, int dp, Copier::Job* jobs)
+{
+    const int row = c->plane_w(p) * c->cfg.bytes_per_sample;
+    const uint8_t* s = static_cast<const uint8_t*>(src);
+    uint8_t* d = static_cast<uint8_t*>(dst);
+    if (!(c->cfg.dh || c->process[p])) {
+        jobs[0] = {d, s, dp, sp, row, c->plane_h_in(p)};
+        return 1;
+    }
+    const int off = field_offset(c, parity), nk = c->plane_h_out(p) / 2, h_out = c->plane_h_out(p);
+    const int first = c->cfg.dh ? 0 : off, step = c->cfg.dh ? 1 : 2;  // kept line k in the source
+    jobs[0] = {d + (size_t)off * dp, s + (size_t)first * sp, 2 * dp, step * sp, row, nk};
+    if (off == 0) jobs[1] = {d + (size_t)(h_out - 1) * dp, s + (size_t)(first + step * (nk - 1)) * sp, dp, sp, row, 1};  // SangNom2.cpp:380-385
+    else jobs[1] = {d, s + (size_t)first * sp, dp, sp, row, 1};                                                       // :386-391
+    return 2;
+}
+
 static int check_planes(Context* c, const void* const src[3], const int32_t sp[3], void* const dst[3],
                         const int32_t dp[3])
 {
@@ -1046,6 +1079,10 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     for (int p = 0; p < c->nplanes(); ++p) {
         // (a plane inside memory the caller pinned is DMA'd as it lies; a pageable one goes through the runtime's own
         // staging -- either way one call)
+        if (!(c->cfg.dh || c->process[p])) {  // a copied plane never visits the device: copy_kept_lines_on_host below
+            if (piped) SN_HIP(c, hipEventRecord(g.arrived[p], g.in));
+            continue;
+        }
         const KeptLines kl = kept_lines(c, p, parity);
         SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p] + (int64_t)kl.first * c->stage_src_pitch[p], (size_t)kl.step * c->stage_src_pitch[p],
                                    static_cast<const uint8_t*>(src[p]) + (int64_t)kl.first * sp[p], (size_t)kl.step * sp[p],
@@ -1064,13 +1101,24 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
         if (piped) (void)hipStreamSynchronize(g.in);  // nothing of this call may still be reading the caller's planes
         return rc;
     }
+    {   // while the device works: the output's kept lines, from the caller's source to the caller's destination
+        Copier::Job jobs[6];
+        int nj = 0;
+        for (int p = 0; p < c->nplanes(); ++p) nj += kept_line_jobs(c, p, parity, src[p], sp[p], dst[p], dp[p], jobs + nj);
+        ensure_copier(c);
+        c->copier->run(jobs, nj);
+    }
     for (int p = 0; p < c->nplanes(); ++p) {
         if (piped) {
             if (!g.recorded[p]) SN_HIP(c, hipEventRecord(g.done[p], c->stream));  // a path that is not written plane by plane: all done here
             SN_HIP(c, hipStreamWaitEvent(g.out, g.done[p], 0));
         }
-        SN_HIP(c, hipMemcpy2DAsync(dst[p], dp[p], c->stage_dst[p], c->stage_dst_pitch[p],
-                                   (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyDeviceToHost, piped ? g.out : c->stream));
+        // only the interpolated lines come back: offset + 1, offset + 3, ... (nr of them)
+        const int off = field_offset(c, parity), nr = c->plane_h_out(p) / 2 - 1;
+        if ((c->cfg.dh || c->process[p]) && nr > 0)
+            SN_HIP(c, hipMemcpy2DAsync(static_cast<uint8_t*>(dst[p]) + (int64_t)(off + 1) * dp[p], (size_t)2 * dp[p],
+                                       c->stage_dst[p] + (int64_t)(off + 1) * c->stage_dst_pitch[p], (size_t)2 * c->stage_dst_pitch[p],
+                                       (size_t)c->plane_w(p) * B, nr, hipMemcpyDeviceToHost, piped ? g.out : c->stream));
     }
     if (piped) SN_HIP(c, hipStreamSynchronize(g.out));
     SN_HIP(c, hipStreamSynchronize(c->stream));
@@ -1116,14 +1164,7 @@ static int ensure_ring(Context* c)
         SN_HIP(c, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
         SN_HIP(c, hipEventCreateWithFlags(&g.swept, hipEventDisableTiming));
     }
-    if (!c->copier) {
-        const char* e = getenv("SN_COPY_THREADS");
-        const unsigned hw = std::thread::hardware_concurrency();
-        int workers = e ? atoi(e) - 1 : (hw >= 8 ? 3 : hw >= 4 ? 1 : 0);
-        if (workers < 0) workers = 0;
-        if (workers > 15) workers = 15;
-        c->copier = new Copier(workers);
-    }
+    ensure_copier(c);
     return SN_OK;
 }
 
