@@ -70,6 +70,7 @@ struct Context {
         int32_t pitch[3] = {0, 0, 0};
         bool direct[3] = {false, false, false};
         bool given = false;
+        bool kept_on_host = false;  // the output's kept lines were copied from the source at submission: only the interpolated lines travel
     };
     std::vector<SlotDst> slot_dst;
     uint8_t* ring_pin_in[3] = {nullptr, nullptr, nullptr};   // [slot][plane bytes], one allocation per plane
@@ -1188,9 +1189,9 @@ static int launch_ring_group(Context* c, int gi)
     SN_HIP(c, hipEventRecord(g.swept, g.stream));
     const int B = c->cfg.bytes_per_sample;
     for (int p = 0; p < c->nplanes(); ++p) {
-        bool any_direct = false;
-        for (int k = 0; k < n; ++k) any_direct = any_direct || c->slot_dst[first + k].direct[p];
-        if (!any_direct) {  // the whole group's plane p in one transfer into the pinned staging
+        bool one_transfer = true;  // the whole group's plane p in one transfer into the pinned staging?
+        for (int k = 0; k < n; ++k) one_transfer = one_transfer && !c->slot_dst[first + k].direct[p] && !c->slot_dst[first + k].kept_on_host;
+        if (one_transfer) {
             SN_HIP(c, hipMemcpyAsync(c->ring_pin_out[p] + (int64_t)first * c->ring_bytes_out[p], ddst[p], (size_t)c->ring_bytes_out[p] * n,
                                      hipMemcpyDeviceToHost, g.stream));
             continue;
@@ -1198,15 +1199,18 @@ static int launch_ring_group(Context* c, int gi)
         for (int k = 0; k < n; ++k) {
             const Context::SlotDst& sd = c->slot_dst[first + k];
             const uint8_t* from = static_cast<const uint8_t*>(ddst[p]) + (int64_t)k * c->ring_bytes_out[p];
-            if (sd.direct[p] && sd.pitch[p] == c->ring_pitch_out[p])  // the caller's pinned plane, same pitch: one linear transfer
-                SN_HIP(c, hipMemcpyAsync(sd.ptr[p], from, (size_t)c->ring_bytes_out[p] - (c->ring_pitch_out[p] - c->plane_w(p) * B),
-                                         hipMemcpyDeviceToHost, g.stream));
-            else if (sd.direct[p])  // ... straight from the device, row by row
-                SN_HIP(c, hipMemcpy2DAsync(sd.ptr[p], sd.pitch[p], from, c->ring_pitch_out[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p),
-                                           hipMemcpyDeviceToHost, g.stream));
-            else
-                SN_HIP(c, hipMemcpyAsync(c->ring_pin_out[p] + (int64_t)(first + k) * c->ring_bytes_out[p], from, (size_t)c->ring_bytes_out[p],
-                                         hipMemcpyDeviceToHost, g.stream));
+            uint8_t* to = sd.direct[p] ? static_cast<uint8_t*>(sd.ptr[p]) : c->ring_pin_out[p] + (int64_t)(first + k) * c->ring_bytes_out[p];
+            const int to_pitch = sd.direct[p] ? sd.pitch[p] : c->ring_pitch_out[p];
+            if (sd.kept_on_host) {  // only the interpolated lines: offset + 1, offset + 3, ...
+                const int off = field_offset(c, c->slot_parity[first + k]), nr = c->plane_h_out(p) / 2 - 1;
+                if ((c->cfg.dh || c->process[p]) && nr > 0)
+                    SN_HIP(c, hipMemcpy2DAsync(to + (int64_t)(off + 1) * to_pitch, (size_t)2 * to_pitch, from + (int64_t)(off + 1) * c->ring_pitch_out[p],
+                                               (size_t)2 * c->ring_pitch_out[p], (size_t)c->plane_w(p) * B, nr, hipMemcpyDeviceToHost, g.stream));
+            } else if (to_pitch == c->ring_pitch_out[p]) {  // same pitch on both sides: one linear transfer
+                SN_HIP(c, hipMemcpyAsync(to, from, (size_t)c->ring_bytes_out[p] - (c->ring_pitch_out[p] - c->plane_w(p) * B), hipMemcpyDeviceToHost, g.stream));
+            } else {  // the caller's pinned plane, row by row
+                SN_HIP(c, hipMemcpy2DAsync(to, to_pitch, from, c->ring_pitch_out[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyDeviceToHost, g.stream));
+            }
         }
     }
     SN_HIP(c, hipEventRecord(g.done, g.stream));
@@ -1258,12 +1262,22 @@ static int submit_impl(sn_context* h, const void* const src[3], const int32_t sp
             sd.direct[p] = sn::plane_is_pinned(dst[p], dp[p], c->plane_w(p) * B, c->plane_h_out(p));
         }
     }
+    // (worth it where the interpolated lines then go straight into the caller's pinned planes; with a pageable destination
+    // the extra host copy at submission costs the submitting thread more than the PCIe crossing it saves)
+    sd.kept_on_host = sd.given;
+    for (int p = 0; p < c->nplanes(); ++p) sd.kept_on_host = sd.kept_on_host && sd.direct[p];
     c->slot_dst[slot] = sd;
-    // source planes: pinned ones are DMA'd as they lie, the others are staged (copy threads) first
-    Copier::Job jobs[3];
+    // source planes: pinned ones are DMA'd as they lie, the others are staged (copy threads) first; with the destination
+    // announced, the output's kept lines (copies of source lines) go there now, on the host
+    Copier::Job jobs[9];
     bool direct_in[3] = {false, false, false};
     int njobs = 0;
+    if (sd.kept_on_host)
+        for (int p = 0; p < c->nplanes(); ++p) njobs += kept_line_jobs(c, p, parity, src[p], sp[p], sd.ptr[p], sd.pitch[p], jobs + njobs);
+    bool on_device[3] = {true, true, true};  // a copied plane whose copy the host has just made never visits the device
     for (int p = 0; p < c->nplanes(); ++p) {
+        on_device[p] = !(sd.kept_on_host && !(c->cfg.dh || c->process[p]));
+        if (!on_device[p]) continue;
         direct_in[p] = sn::plane_is_pinned(src[p], sp[p], c->plane_w(p) * B, c->plane_h_in(p));
         if (!direct_in[p]) {
             const KeptLines kl = kept_lines(c, p, parity);  // only the lines that are read are staged ...
@@ -1274,6 +1288,7 @@ static int submit_impl(sn_context* h, const void* const src[3], const int32_t sp
     }
     if (njobs) c->copier->run(jobs, njobs);
     for (int p = 0; p < c->nplanes(); ++p) {
+        if (!on_device[p]) continue;
         uint8_t* dev = c->ring_dev_in[p] + (int64_t)slot * c->ring_bytes_in[p];
         const KeptLines kl = kept_lines(c, p, parity);  // ... and cross PCIe
         const uint8_t* from = direct_in[p] ? static_cast<const uint8_t*>(src[p]) : c->ring_pin_in[p] + (int64_t)slot * c->ring_bytes_in[p];
@@ -1336,6 +1351,15 @@ int sn_collect_host(sn_context* h, int32_t slot, void* const dst_arg[3], const i
         const uint8_t* from = c->ring_pin_out[p] + (int64_t)slot * c->ring_bytes_out[p];
         if (sd.direct[p]) {  // collected into another place than announced: that plane never reached the staging
             SN_HIP(c, hipMemcpy2D(dst[p], dp[p], sd.ptr[p], sd.pitch[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyHostToHost));
+            continue;
+        }
+        if (sd.kept_on_host) {  // the staging holds the interpolated lines only; the kept ones went to the announced planes at submission
+            const int off = field_offset(c, c->slot_parity[slot]), nr = c->plane_h_out(p) / 2 - 1;
+            if (dst[p] != sd.ptr[p])  // ... which is not where the frame is collected: take them from there
+                SN_HIP(c, hipMemcpy2D(dst[p], dp[p], sd.ptr[p], sd.pitch[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyHostToHost));
+            if ((c->cfg.dh || c->process[p]) && nr > 0)
+                jobs[njobs++] = {static_cast<uint8_t*>(dst[p]) + (size_t)(off + 1) * dp[p], from + (size_t)(off + 1) * c->ring_pitch_out[p], 2 * dp[p],
+                                 2 * c->ring_pitch_out[p], c->plane_w(p) * B, nr};
             continue;
         }
         jobs[njobs++] = {static_cast<uint8_t*>(dst[p]), from, dp[p], c->ring_pitch_out[p], c->plane_w(p) * B, c->plane_h_out(p)};

@@ -53,6 +53,29 @@ def main():
                 flt.collect(inflight.pop(0), dst)
             out[f"ring{slots}_fps"] = round(a.frames / (time.perf_counter() - t0), 1)
 
+    # pageable frames, the destination named at submission (what GetFrame has: NewVideoFrame precedes the work): the
+    # output's kept lines are copied on the host at submission, only the interpolated lines come back over PCIe
+    for depth in [int(x) for x in a.depths.split(",")][-3:]:
+        with SangNom2(clip, host_depth=depth, **kw) as flt:
+            slots = flt.host_slots()
+            dsts = [[np.zeros(flt.plane_shape_out(p), dtype=clip.dtype) for p in range(flt.nplanes)] for _ in range(slots)]
+            inflight = []
+            for f in range(slots):
+                inflight.append((flt.submit(ring[f % 8], dst=dsts[f % slots]), dsts[f % slots]))
+            while inflight:
+                sl, d = inflight.pop(0)
+                flt.collect(sl, d, announced=True)
+            t0 = time.perf_counter()
+            for f in range(a.frames):
+                if len(inflight) == slots:
+                    sl, d = inflight.pop(0)
+                    flt.collect(sl, d, announced=True)
+                inflight.append((flt.submit(ring[f % 8], dst=dsts[f % slots]), dsts[f % slots]))
+            while inflight:
+                sl, d = inflight.pop(0)
+                flt.collect(sl, d, announced=True)
+            out[f"ring{slots}_to_fps"] = round(a.frames / (time.perf_counter() - t0), 1)
+
     # the same with the host's frames in pinned memory (sn_pin_host_buffer) and the destination named at submission
     from avisynth_sangnom2_amd import pin_host_array, unpin_host_array
     for depth in [int(x) for x in a.depths.split(",")][-3:]:
