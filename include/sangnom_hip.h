@@ -125,7 +125,11 @@ const char* sn_last_error(const sn_context* ctx);
 
 /* One GetFrame (src/SangNom2.cpp:332-397) with HOST planes: H2D, kernels, D2H, synchronous.
  * src planes have the input geometry, dst planes the output geometry; pitches in bytes, any
- * value >= row size.  parity = child->GetParity(n), used only when order == 0. */
+ * value >= row size.  parity = child->GetParity(n), used only when order == 0.
+ * Only the lines the filter reads (the kept field of a processed plane) are sent to the device, and only the
+ * interpolated lines come back: the kept lines of the output -- copies of source lines, src/SangNom2.cpp:361-391 --
+ * and planes that are merely copied are written from src to dst on the host meanwhile.  src and dst planes must
+ * not overlap. */
 int sn_process_host(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3],
                     void* const dst[3], const int32_t dst_pitch[3], int32_t parity);
 
@@ -164,7 +168,10 @@ int sn_collect_host(sn_context* ctx, int32_t slot, void* const dst[3], const int
  * -- sn_submit_host with the destination planes named at submission, as a plugin's GetFrame has them
  * (env->NewVideoFrame before the kernel runs, src/SangNom2.cpp:344) -- has the output written straight into them;
  * sn_collect_host (dst = NULL allowed then) only waits.  Unpinned planes take the staged route as before, plane by
- * plane.  Process-wide registry, thread-safe. */
+ * plane.  When every destination plane of a submission is pinned, the kept lines of the output are copied from src
+ * to dst on the host during sn_submit_host_to and only the interpolated lines cross PCIe afterwards: the caller must
+ * leave the announced planes alone until the slot is collected (and src, dst must not overlap).  Process-wide
+ * registry, thread-safe. */
 int sn_pin_host_buffer(void* ptr, size_t bytes);
 int sn_unpin_host_buffer(void* ptr);
 int sn_submit_host_to(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3], void* const dst[3],
