@@ -1080,7 +1080,7 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     for (int p = 0; p < c->nplanes(); ++p) {
         // (a plane inside memory the caller pinned is DMA'd as it lies; a pageable one goes through the runtime's own
         // staging -- either way one call)
-        if (!(c->cfg.dh || c->process[p])) {  // a copied plane never visits the device: copy_kept_lines_on_host below
+        if (!(c->cfg.dh || c->process[p])) {  // a copied plane never visits the device: the host copies it (kept_line_jobs below)
             if (piped) SN_HIP(c, hipEventRecord(g.arrived[p], g.in));
             continue;
         }
