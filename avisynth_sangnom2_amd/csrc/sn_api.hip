@@ -797,7 +797,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks_dev));
         a.guard = fp.band_flags;
         pool.guard = fp.band_flags;
-        SN_HIP(c, sn::launch_assemble(st, a, B, n));
+        // (no k_assemble: the kept lines the bands have copied are right whatever the check says)
         SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(p), n, slot0));
         return SN_OK;
     };
@@ -895,8 +895,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         sn::PoolArgs pool = c->pool;
         pool.guard = fp.band_flags;
         pool.rows = stop[0];
-        SN_HIP(c, sn::launch_assemble(st, a, B, n));
-        SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(0), n, slot0));
+        SN_HIP(c, sn::launch_pool_plane(st, a, pool, B, c->threshold(0), n, slot0));  // (kept lines: already copied by the bands)
         SN_HIP(c, plane_out(0));
         for (int p = 1; p < 3; ++p) {
             pool = c->pool;
