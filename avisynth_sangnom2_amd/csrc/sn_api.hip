@@ -104,8 +104,8 @@ struct Context {
     std::string err;
 
     // row-band sweeps of small launches (sn_fused_v3_common.h): per scratch slot the bands' state
-    // snapshots and the frame's flag; the verification counts failed frames in band_fallbacks_dev, copied to the
-    // pinned band_fallbacks behind every banded launch
+    // snapshots and the frame's flag; the verification counts failed frames in band_fallbacks_dev and mirrors the count
+    // into band_fallbacks, host memory the device can write (what the pause heuristic of band_count looks at)
     uint32_t* band_state = nullptr;
     int32_t* band_flags = nullptr;
     int64_t* band_fallbacks = nullptr;
@@ -689,7 +689,7 @@ static int ensure_bands(Context* c)
     SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->band_fallbacks_dev), sizeof(int64_t)));
     SN_HIP(c, hipMemsetAsync(c->band_fallbacks_dev, 0, sizeof(int64_t), c->stream));
     SN_HIP(c, hipStreamSynchronize(c->stream));
-    SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->band_fallbacks), sizeof(int64_t), hipHostMallocDefault));
+    SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->band_fallbacks), sizeof(int64_t), hipHostMallocMapped));
     *c->band_fallbacks = 0;
     return SN_OK;
 }
@@ -794,7 +794,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         else if (B == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), n, &fp));
         else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), n, &fp));
         const int threads = 64 * (B == 4 ? sn::fused_f32_waves(a.w) : B == 2 ? sn::fused_u16_waves(a.w) : sn::fused_v3_waves(a.w));
-        SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks_dev));
+        SN_HIP(c, sn::launch_band_verify(st, fp.band_state, threads, fp.nbands, n, fp.band_flags, c->band_fallbacks_dev, c->band_fallbacks));
         a.guard = fp.band_flags;
         pool.guard = fp.band_flags;
         // (no k_assemble: the kept lines the bands have copied are right whatever the check says)
@@ -820,7 +820,6 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
             if (rc != SN_OK) return rc;
             SN_HIP(c, plane_out(p));
         }
-        SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         c->fused_frames += n;
         c->banded_frames += n;
         return SN_OK;
@@ -888,8 +887,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         if (B == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, pa[0], c->threshold(0), n, &fp));
         else if (B == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, pa[0], c->threshold(0), n, &fp));
         else SN_HIP(c, sn::launch_fused_u8_v3(st, pa[0], c->threshold(0), n, &fp));
-        SN_HIP(c, sn::launch_band_verify(st, fp.band_state, band_threads(c), fp.nbands, n, fp.band_flags, c->band_fallbacks_dev));
-        SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        SN_HIP(c, sn::launch_band_verify(st, fp.band_state, band_threads(c), fp.nbands, n, fp.band_flags, c->band_fallbacks_dev, c->band_fallbacks));
         sn::PlaneArgs a = pa[0];
         a.guard = fp.band_flags;
         sn::PoolArgs pool = c->pool;
@@ -962,7 +960,6 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
             if (rc != SN_OK) return rc;
             SN_HIP(c, plane_out(p));
         }
-        SN_HIP(c, hipMemcpyAsync(c->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         c->fused_frames += n;
         c->banded_frames += n;
         return SN_OK;
@@ -1454,7 +1451,11 @@ int sn_get_info(sn_context* h, sn_info* info)
     info->coupled_rows = c->fused420 ? c->fpool_rows : 0;
     info->reserved0 = 0;
     info->banded_frames = c->banded_frames;
-    info->band_fallbacks = c->band_fallbacks ? *c->band_fallbacks : 0;
+    info->band_fallbacks = 0;
+    if (c->band_fallbacks_dev) {  // the device's own count (the host mirror may lag behind a launch with several failing frames)
+        SN_HIP(c, hipSetDevice(c->device));
+        SN_HIP(c, hipMemcpy(&info->band_fallbacks, c->band_fallbacks_dev, sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
     for (int p = 0; p < 3; ++p) info->threshold[p] = p < c->nplanes() ? c->threshold(p) : 0.0;
     return SN_OK;
 }

@@ -13,7 +13,8 @@
 
 namespace sn {
 
-__global__ void __launch_bounds__(256) k_band_verify(const uint32_t* state, int words, int nbands, int32_t* flags, int64_t* fallbacks)
+__global__ void __launch_bounds__(256) k_band_verify(const uint32_t* state, int words, int nbands, int32_t* flags, int64_t* fallbacks,
+                                                     int64_t* host_mirror)
 {
     const int b = blockIdx.x, f = blockIdx.y;
     const uint4* end = reinterpret_cast<const uint4*>(state + ((int64_t)(f * nbands + b) * 2 + 1) * words);
@@ -24,14 +25,18 @@ __global__ void __launch_bounds__(256) k_band_verify(const uint32_t* state, int 
         diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
     }
     if (__syncthreads_or(diff != 0) && threadIdx.x == 0) {
-        if (atomicExch(&flags[f], 1) == 0 && fallbacks) atomicAdd(reinterpret_cast<unsigned long long*>(fallbacks), 1ull);
+        if (atomicExch(&flags[f], 1) == 0 && fallbacks) {
+            const unsigned long long count = atomicAdd(reinterpret_cast<unsigned long long*>(fallbacks), 1ull) + 1ull;
+            if (host_mirror) __hip_atomic_store(host_mirror, (int64_t)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
-hipError_t launch_band_verify(hipStream_t s, const uint32_t* state, int threads, int nbands, int nframes, int32_t* flags, int64_t* fallbacks)
+hipError_t launch_band_verify(hipStream_t s, const uint32_t* state, int threads, int nbands, int nframes, int32_t* flags, int64_t* fallbacks,
+                              int64_t* host_mirror)
 {
     if (nbands < 2) return hipSuccess;
-    hipLaunchKernelGGL(k_band_verify, dim3(nbands - 1, nframes), dim3(256), 0, s, state, kBuffers * 8 * threads, nbands, flags, fallbacks);
+    hipLaunchKernelGGL(k_band_verify, dim3(nbands - 1, nframes), dim3(256), 0, s, state, kBuffers * 8 * threads, nbands, flags, fallbacks, host_mirror);
     return hipGetLastError();
 }
 

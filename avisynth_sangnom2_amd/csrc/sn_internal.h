@@ -80,9 +80,11 @@ struct FusedPool {
 };
 // sn_band.hip: words of band state per frame for a sweep of `threads` threads; the check of a band launch -- flags[f] != 0
 // afterwards means frame f has to be redone by the pool path (its guarded launches look at the same flags);
-// *fallbacks (device memory, may be null) counts such frames.
+// *fallbacks (device memory, may be null) counts such frames, *host_mirror (host memory the device can write, may be
+// null) receives the count as well.
 inline int64_t band_state_words(int threads, int nbands) { return (int64_t)nbands * 2 * kBuffers * 8 * threads; }
-hipError_t launch_band_verify(hipStream_t s, const uint32_t* state, int threads, int nbands, int nframes, int32_t* flags, int64_t* fallbacks);
+hipError_t launch_band_verify(hipStream_t s, const uint32_t* state, int threads, int nbands, int nframes, int32_t* flags, int64_t* fallbacks,
+                              int64_t* host_mirror);
 int fused_v3_waves(int sweep_w);
 int64_t fused_v3_pool_bytes(int sweep_w, int rows);
 // host: scatter one scratch pool (thread-slot layout) into [9][rows][sweep_w] samples (test hook)
