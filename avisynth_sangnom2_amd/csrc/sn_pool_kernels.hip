@@ -7,6 +7,7 @@
 // are not a multiple of 32 carry pool state from frame to frame).  It is also the exact fallback
 // of the fused kernel.  Stage 2 is a strictly sequential recurrence over rows
 // (SangNom2.cpp:126-159), so k_smooth walks the rows with one workgroup per buffer.
+#include "sn_fused_v3_common.h"
 #include "sn_internal.h"
 #include "sn_pixel.h"
 
@@ -285,6 +286,122 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, i
         prev = o;
         cur = nxt;
         nxt = unpack(pre);
+    };
+    for (int r = 1; r < rows; r += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (r + u < rows) {  // uniform
+                const uint2 pre = ring[u];
+                ring[u] = load(row_or_last(r + u + 2 + kAhead));
+                row_step(r + u, pre);
+            }
+        }
+    }
+}
+
+// 8-bit pools of 512 columns and more, second cut: no barrier per row.  The pool row is cut into strips of 60 lanes x 8
+// columns, one wave each, exactly like the fused sweeps (sn_fused_v3_common.h): inside a wave the neighbours' sums come
+// over DPP, and two ghost lanes on either inner side of a strip repeat the neighbouring wave's seam columns, good for
+// K = 5 rows (the box spreads 3 columns a row over their 16), after which they take the seam lanes' state from an LDS
+// mailbox -- one barrier every five rows instead of one per row, no LDS on the row's critical path.  Waves drift by
+// up to four rows between barriers, and the rows are smoothed IN PLACE: a lane fetches pool row r + 2 + kAhead while it
+// works on row r, i.e. before the wave that owns those columns (at most four rows ahead) can have overwritten it.
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs pool, int slot0)
+{
+    using namespace v3c;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;
+    const int nl = se >> 3;             // lanes that own columns
+    const int nw = (int)blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const int f = blockIdx.y;
+    if (pool.guard && pool.guard[f] == 0) return;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    uint8_t* buf = pool.base + (int64_t)(slot0 + f) * pool.slot_bytes + (size_t)b * bufsz;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int gl;
+    bool ghost;
+    if (wave == 0) {
+        gl = lane;
+        ghost = nw > 1 && lane >= 64 - GH;
+    } else {
+        gl = kFirst + kInner * (wave - 1) + (lane - GH);
+        ghost = lane < GH || (lane >= 64 - GH && wave < nw - 1);
+    }
+    const bool live = gl < nl, real = live && !ghost;
+    const int x0 = live ? gl * 8 : 0;  // dead lanes shadow column 0 and store nothing
+    const unsigned first_mask = live && gl == 0 ? 0xffffffffu : 0u, last_mask = live && gl == nl - 1 ? 0xffffffffu : 0u;
+    // mailbox: [copy][wave][side][slot][4 registers]
+    unsigned* mb = reinterpret_cast<unsigned*>(smem);
+    auto mb_at = [&](int copy, int w, int side, int slot) { return mb + ((((copy * nw + w) * 2 + side) * GH + slot) * 4); };
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < nw - 1;  // feeds the next wave's left ghosts
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;                   // ... the previous wave's right ghosts
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    struct Row {
+        unsigned v[4];  // columns x0 + 2i | x0 + 2i + 1 << 16
+    };
+    auto unpack = [](uint2 q) {
+        Row r;
+        r.v[0] = __builtin_amdgcn_perm(0u, q.x, 0x0c010c00u);
+        r.v[1] = __builtin_amdgcn_perm(0u, q.x, 0x0c030c02u);
+        r.v[2] = __builtin_amdgcn_perm(0u, q.y, 0x0c010c00u);
+        r.v[3] = __builtin_amdgcn_perm(0u, q.y, 0x0c030c02u);
+        return r;
+    };
+    auto load = [&](int row) { return *reinterpret_cast<const uint2*>(buf + (size_t)row * se + x0); };
+    auto row_or_last = [&](int row) { return row <= pool.bh ? row : pool.bh; };  // past the end: loaded, never used
+    constexpr int kAhead = K;  // >= the drift between two waves + 1
+    Row prev = unpack(load(0)), cur = unpack(load(1)), nxt = unpack(load(row_or_last(2)));
+    uint2 ring[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) ring[u] = load(row_or_last(3 + u));
+    __syncthreads();  // nobody stores before everybody has fetched its first rows
+    const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    auto row_step = [&](int r, uint2 pre) {  // pre = row r + 2
+        if (r > 1 && (r - 1) % K == 0) {  // the ghosts take over what the seam lanes held after row r - 1
+            __syncthreads();
+            if (recv) {
+                const unsigned* from = mb_at((r / K) & 1, wave, lane < GH ? 0 : 1, slot);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) prev.v[i] = from[i];
+            }
+        }
+        unsigned E[8];  // E[2 + j] = sums of columns x0 + 2j | x0 + 2j + 1, j = -2 .. 5
+#pragma unroll
+        for (int i = 0; i < 4; ++i) E[2 + i] = prev.v[i] + cur.v[i] + nxt.v[i];
+        // the neighbouring lanes' sums; the pool row is clamped at both ends (SangNom2.cpp:144-150).  Bitwise selects:
+        // a DPP read under a lane mask would see the masked-off lanes as zero.
+        const unsigned left_edge = (E[2] & 0xffffu) * 0x10001u, right_edge = (E[5] >> 16) * 0x10001u;
+        E[0] = (first_mask & left_edge) | (~first_mask & dpp_from_left(E[4]));
+        E[1] = (first_mask & left_edge) | (~first_mask & dpp_from_left(E[5]));
+        E[6] = (last_mask & right_edge) | (~last_mask & dpp_from_right(E[2]));
+        E[7] = (last_mask & right_edge) | (~last_mask & dpp_from_right(E[3]));
+        unsigned O[7];  // O[j] = sums of columns x0 + 2j - 3 | x0 + 2j - 2
+#pragma unroll
+        for (int j = 0; j < 7; ++j) O[j] = __builtin_amdgcn_alignbit(E[j + 1], E[j], 16);
+        unsigned T = ((O[0] + E[1]) + (O[1] + E[2])) + ((O[2] + E[3]) + O[3]);
+        Row o;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            o.v[m] = (T >> 4) & 0x00ff00ffu;  // (sum / 16) wraps to uint8_t, SangNom2.cpp:152; integer sums: any order
+            if (m < 3) T = (T - O[m] - E[1 + m]) + (E[4 + m] + O[m + 4]);
+        }
+        if (real) {
+            uint2 q;
+            q.x = __builtin_amdgcn_perm(o.v[1], o.v[0], 0x06040200u);
+            q.y = __builtin_amdgcn_perm(o.v[3], o.v[2], 0x06040200u);
+            *reinterpret_cast<uint2*>(buf + (size_t)r * se + x0) = q;
+        }
+        prev = o;
+        cur = nxt;
+        nxt = unpack(pre);
+        if (r % K == 0 && r < rows - 1 && (pub_right || pub_left)) {
+            unsigned* to = pub_right ? mb_at(((r + 1) / K) & 1, wave + 1, 0, slot) : mb_at(((r + 1) / K) & 1, wave - 1, 1, slot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) to[i] = prev.v[i];
+        }
     };
     for (int r = 1; r < rows; r += kAhead) {
 #pragma unroll
@@ -593,7 +710,11 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
         dim3 grid((p.w + 255) / 256, nr, nframes), block(256);
         hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, p, pool, slot0);
     }
-    if (std::is_same<T, uint8_t>::value && pool.bh > 1 && pool.stride_e >= 256 && pool.stride_e <= 8 * kSmoothThreads) {
+    if (std::is_same<T, uint8_t>::value && pool.bh > 1 && pool.stride_e >= 512 && v3c::strips_for(pool.stride_e / 8) <= kSmoothThreads / 64) {
+        const int nw = v3c::strips_for(pool.stride_e / 8);
+        const size_t lds = (size_t)2 * nw * 2 * v3c::GH * 4 * sizeof(unsigned);
+        hipLaunchKernelGGL(k_smooth_u8_strips, dim3(kBuffers, nframes), dim3(nw * 64), lds, st, pool, slot0);
+    } else if (std::is_same<T, uint8_t>::value && pool.bh > 1 && pool.stride_e >= 256 && pool.stride_e <= 8 * kSmoothThreads) {
         const int threads = ((pool.stride_e / 8) + 63) / 64 * 64;
         const size_t lds = (size_t)2 * (pool.stride_e / 8) * sizeof(uint4);
         hipLaunchKernelGGL(k_smooth_u8x2, dim3(kBuffers, nframes), dim3(threads), lds, st, pool, slot0);
