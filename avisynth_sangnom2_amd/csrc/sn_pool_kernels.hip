@@ -503,6 +503,117 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, 
     }
 }
 
+// 9..16-bit pools of 512 columns and more in strips, as k_smooth_u8_strips: 60 lanes x 8 columns per wave, one 32-bit
+// sum per register, the three sums on either side over DPP, ghost lanes refreshed from the mailbox every K rows.
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_strips(PoolArgs pool, int slot0)
+{
+    using namespace v3c;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;
+    const int nl = se >> 3;             // lanes that own columns
+    const int nw = (int)blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const int f = blockIdx.y;
+    if (pool.guard && pool.guard[f] == 0) return;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int gl;
+    bool ghost;
+    if (wave == 0) {
+        gl = lane;
+        ghost = nw > 1 && lane >= 64 - GH;
+    } else {
+        gl = kFirst + kInner * (wave - 1) + (lane - GH);
+        ghost = lane < GH || (lane >= 64 - GH && wave < nw - 1);
+    }
+    const bool live = gl < nl, real = live && !ghost;
+    const int x0 = live ? gl * 8 : 0;  // dead lanes shadow column 0 and store nothing
+    const unsigned first_mask = live && gl == 0 ? 0xffffffffu : 0u, last_mask = live && gl == nl - 1 ? 0xffffffffu : 0u;
+    // mailbox: [copy][wave][side][slot][8 registers]
+    unsigned* mb = reinterpret_cast<unsigned*>(smem);
+    auto mb_at = [&](int copy, int w, int side, int slot) { return mb + ((((copy * nw + w) * 2 + side) * GH + slot) * 8); };
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < nw - 1;  // feeds the next wave's left ghosts
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;                   // ... the previous wave's right ghosts
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    struct Row {
+        unsigned v[8];
+    };
+    auto unpack = [](uint4 q) {
+        Row r;
+        r.v[0] = q.x & 0xffffu; r.v[1] = q.x >> 16;
+        r.v[2] = q.y & 0xffffu; r.v[3] = q.y >> 16;
+        r.v[4] = q.z & 0xffffu; r.v[5] = q.z >> 16;
+        r.v[6] = q.w & 0xffffu; r.v[7] = q.w >> 16;
+        return r;
+    };
+    auto load = [&](int row) { return *reinterpret_cast<const uint4*>(buf + (size_t)row * se + x0); };
+    auto row_or_last = [&](int row) { return row <= pool.bh ? row : pool.bh; };  // past the end: loaded, never used
+    constexpr int kAhead = K;  // >= the drift between two waves + 1
+    Row prev = unpack(load(0)), cur = unpack(load(1)), nxt = unpack(load(row_or_last(2)));
+    uint4 ring[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) ring[u] = load(row_or_last(3 + u));
+    __syncthreads();  // nobody stores before everybody has fetched its first rows
+    const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    auto row_step = [&](int r, uint4 pre) {  // pre = row r + 2
+        if (r > 1 && (r - 1) % K == 0) {  // the ghosts take over what the seam lanes held after row r - 1
+            __syncthreads();
+            if (recv) {
+                const uint4* from = reinterpret_cast<const uint4*>(mb_at((r / K) & 1, wave, lane < GH ? 0 : 1, slot));
+                const uint4 a = from[0], c = from[1];
+                prev.v[0] = a.x; prev.v[1] = a.y; prev.v[2] = a.z; prev.v[3] = a.w;
+                prev.v[4] = c.x; prev.v[5] = c.y; prev.v[6] = c.z; prev.v[7] = c.w;
+            }
+        }
+        unsigned X[14];  // sums of columns x0 - 3 .. x0 + 10
+#pragma unroll
+        for (int i = 0; i < 8; ++i) X[3 + i] = prev.v[i] + cur.v[i] + nxt.v[i];
+        // the pool row is clamped at both ends (SangNom2.cpp:144-150); bitwise selects, as in k_smooth_u8_strips
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            X[i] = (first_mask & X[3]) | (~first_mask & dpp_from_left(X[8 + i]));
+            X[11 + i] = (last_mask & X[10]) | (~last_mask & dpp_from_right(X[3 + i]));
+        }
+        unsigned T = ((X[0] + X[1]) + X[2]) + ((X[3] + X[4]) + (X[5] + X[6]));
+        Row o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o.v[k] = (T >> 4) & 0xffffu;  // (sum / 16) wraps to uint16_t, SangNom2.cpp:152; integer sums: any order
+            if (k < 7) T = (T - X[k]) + X[k + 7];
+        }
+        if (real) {
+            uint4 q;
+            q.x = o.v[0] | (o.v[1] << 16);
+            q.y = o.v[2] | (o.v[3] << 16);
+            q.z = o.v[4] | (o.v[5] << 16);
+            q.w = o.v[6] | (o.v[7] << 16);
+            *reinterpret_cast<uint4*>(buf + (size_t)r * se + x0) = q;
+        }
+        prev = o;
+        cur = nxt;
+        nxt = unpack(pre);
+        if (r % K == 0 && r < rows - 1 && (pub_right || pub_left)) {
+            uint4* to = reinterpret_cast<uint4*>(pub_right ? mb_at(((r + 1) / K) & 1, wave + 1, 0, slot)
+                                                           : mb_at(((r + 1) / K) & 1, wave - 1, 1, slot));
+            to[0] = make_uint4(prev.v[0], prev.v[1], prev.v[2], prev.v[3]);
+            to[1] = make_uint4(prev.v[4], prev.v[5], prev.v[6], prev.v[7]);
+        }
+    };
+    for (int r = 1; r < rows; r += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (r + u < rows) {  // uniform
+                const uint4 pre = ring[u];
+                ring[u] = load(row_or_last(r + u + 2 + kAhead));
+                row_step(r + u, pre);
+            }
+        }
+    }
+}
+
 // Float pools: eight columns per thread too.  The sums keep the reference's order -- (a + b) + c for the three rows, the
 // seven taps left to right (SangNom2.cpp:144-152) -- so nothing slides; what is saved is the per-thread overhead (half
 // the waves, one 32-byte row access, two 16-byte LDS reads per thread and row) and the row latency (four rows in flight).
@@ -718,6 +829,10 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
         const int threads = ((pool.stride_e / 8) + 63) / 64 * 64;
         const size_t lds = (size_t)2 * (pool.stride_e / 8) * sizeof(uint4);
         hipLaunchKernelGGL(k_smooth_u8x2, dim3(kBuffers, nframes), dim3(threads), lds, st, pool, slot0);
+    } else if (std::is_same<T, uint16_t>::value && pool.bh > 1 && pool.stride_e >= 512 && v3c::strips_for(pool.stride_e / 8) <= kSmoothThreads / 64) {
+        const int nw = v3c::strips_for(pool.stride_e / 8);
+        const size_t lds = (size_t)2 * nw * 2 * v3c::GH * 8 * sizeof(unsigned);
+        hipLaunchKernelGGL(k_smooth_u16_strips, dim3(kBuffers, nframes), dim3(nw * 64), lds, st, pool, slot0);
     } else if (std::is_same<T, uint16_t>::value && pool.bh > 1 && pool.stride_e >= 256 && pool.stride_e <= 8 * kSmoothThreads) {
         const int threads = ((pool.stride_e / 8) + 63) / 64 * 64;
         const size_t lds = (size_t)2 * 2 * (pool.stride_e / 8) * sizeof(uint4);
