@@ -704,6 +704,121 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32x8(PoolArgs pool, 
 
 // Pools narrower than 1024 columns: one column per thread, columns strided by the workgroup size.  (Measured on
 // 720-wide clips: 12 % faster per row than the NC = 1 instance of the kernel above, which wins from 1024 columns on.)
+// Float pools of 512 columns and more in strips, as k_smooth_u16_strips; every sum in the reference's order.  What the
+// ghost lanes of a strip's outer lanes compute after the seam (anything, NaN included) never reaches an owned column
+// inside the K rows between two refreshes.
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_strips(PoolArgs pool, int slot0)
+{
+    using namespace v3c;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;
+    const int nl = se >> 3;             // lanes that own columns
+    const int nw = (int)blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const int f = blockIdx.y;
+    if (pool.guard && pool.guard[f] == 0) return;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    float* buf = reinterpret_cast<float*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int gl;
+    bool ghost;
+    if (wave == 0) {
+        gl = lane;
+        ghost = nw > 1 && lane >= 64 - GH;
+    } else {
+        gl = kFirst + kInner * (wave - 1) + (lane - GH);
+        ghost = lane < GH || (lane >= 64 - GH && wave < nw - 1);
+    }
+    const bool live = gl < nl, real = live && !ghost;
+    const int x0 = live ? gl * 8 : 0;  // dead lanes shadow column 0 and store nothing
+    const unsigned first_mask = live && gl == 0 ? 0xffffffffu : 0u, last_mask = live && gl == nl - 1 ? 0xffffffffu : 0u;
+    // mailbox: [copy][wave][side][slot][8 registers]
+    float* mb = reinterpret_cast<float*>(smem);
+    auto mb_at = [&](int copy, int w, int side, int slot) { return mb + ((((copy * nw + w) * 2 + side) * GH + slot) * 8); };
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < nw - 1;  // feeds the next wave's left ghosts
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;                   // ... the previous wave's right ghosts
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    struct Row {
+        float v[8];
+    };
+    auto from_vec = [](float4 a, float4 c) {
+        Row r;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+        r.v[4] = c.x; r.v[5] = c.y; r.v[6] = c.z; r.v[7] = c.w;
+        return r;
+    };
+    struct Raw {
+        float4 lo, hi;
+    };
+    auto load = [&](int row) {
+        const float4* p = reinterpret_cast<const float4*>(buf + (size_t)row * se + x0);
+        Raw q;
+        q.lo = p[0];
+        q.hi = p[1];
+        return q;
+    };
+    auto unpack = [&](const Raw& q) { return from_vec(q.lo, q.hi); };
+    auto row_or_last = [&](int row) { return row <= pool.bh ? row : pool.bh; };  // past the end: loaded, never used
+    constexpr int kAhead = K;  // >= the drift between two waves + 1
+    Row prev = unpack(load(0)), cur = unpack(load(1)), nxt = unpack(load(row_or_last(2)));
+    Raw ring[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) ring[u] = load(row_or_last(3 + u));
+    __syncthreads();  // nobody stores before everybody has fetched its first rows
+    const int rows = pool.rows > 0 && pool.rows < pool.bh ? pool.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    auto pick = [](unsigned mask, float edge, float other) {  // bitwise, as in k_smooth_u8_strips
+        return __uint_as_float((mask & __float_as_uint(edge)) | (~mask & __float_as_uint(other)));
+    };
+    auto row_step = [&](int r, const Raw& pre) {  // pre = row r + 2
+        if (r > 1 && (r - 1) % K == 0) {  // the ghosts take over what the seam lanes held after row r - 1
+            __syncthreads();
+            if (recv) {
+                const float4* from = reinterpret_cast<const float4*>(mb_at((r / K) & 1, wave, lane < GH ? 0 : 1, slot));
+                prev = from_vec(from[0], from[1]);
+            }
+        }
+        float X[14];  // sums of columns x0 - 3 .. x0 + 10
+#pragma unroll
+        for (int i = 0; i < 8; ++i) X[3 + i] = (prev.v[i] + cur.v[i]) + nxt.v[i];
+        // the pool row is clamped at both ends (SangNom2.cpp:144-150)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            X[i] = pick(first_mask, X[3], __uint_as_float(dpp_from_left(__float_as_uint(X[8 + i]))));
+            X[11 + i] = pick(last_mask, X[10], __uint_as_float(dpp_from_right(__float_as_uint(X[3 + i]))));
+        }
+        Row o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)  // left to right, SangNom2.cpp:152
+            o.v[k] = ((((((X[k] + X[k + 1]) + X[k + 2]) + X[k + 3]) + X[k + 4]) + X[k + 5]) + X[k + 6]) * 0.0625f;
+        if (real) {
+            float4* q = reinterpret_cast<float4*>(buf + (size_t)r * se + x0);
+            q[0] = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
+            q[1] = make_float4(o.v[4], o.v[5], o.v[6], o.v[7]);
+        }
+        prev = o;
+        cur = nxt;
+        nxt = unpack(pre);
+        if (r % K == 0 && r < rows - 1 && (pub_right || pub_left)) {
+            float4* to = reinterpret_cast<float4*>(pub_right ? mb_at(((r + 1) / K) & 1, wave + 1, 0, slot)
+                                                             : mb_at(((r + 1) / K) & 1, wave - 1, 1, slot));
+            to[0] = make_float4(prev.v[0], prev.v[1], prev.v[2], prev.v[3]);
+            to[1] = make_float4(prev.v[4], prev.v[5], prev.v[6], prev.v[7]);
+        }
+    };
+    for (int r = 1; r < rows; r += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (r + u < rows) {  // uniform
+                const Raw pre = ring[u];
+                ring[u] = load(row_or_last(r + u + 2 + kAhead));
+                row_step(r + u, pre);
+            }
+        }
+    }
+}
+
 template <class T, int NC>
 __global__ void __launch_bounds__(kSmoothThreads) k_smooth_strided(PoolArgs pool, int slot0)
 {
@@ -840,6 +955,13 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
         if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)k_smooth_u16x8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_smooth_u16x8, dim3(kBuffers, nframes), dim3(threads), lds, st, pool, slot0);
+    } else if (std::is_same<T, float>::value && pool.bh > 1 && pool.stride_e >= 512 && v3c::strips_for(pool.stride_e / 8) <= kSmoothThreads / 64 &&
+               nframes <= 8) {
+        // launches of more frames are bound by HBM, where the ghost lanes' second fetch of the seam columns costs more
+        // than the barriers saved (sixteen 2160p frames: 6.3 k frames/s with k_smooth_f32x8, 5.9 k in strips)
+        const int nw = v3c::strips_for(pool.stride_e / 8);
+        const size_t lds = (size_t)2 * nw * 2 * v3c::GH * 8 * sizeof(float);
+        hipLaunchKernelGGL(k_smooth_f32_strips, dim3(kBuffers, nframes), dim3(nw * 64), lds, st, pool, slot0);
     } else if (std::is_same<T, float>::value && pool.bh > 1 && pool.stride_e >= 256 && pool.stride_e <= 8 * kSmoothThreads) {
         const int threads = ((pool.stride_e / 8) + 63) / 64 * 64;
         const size_t lds = (size_t)2 * 2 * (pool.stride_e / 8) * sizeof(float4);
