@@ -3,11 +3,14 @@
 tools/latency_bench.py [--fmt Y8] [--w 3840] [--h 2160] [--bands N] [--warm N]"""
 import argparse
 import json
+import os
+import sys
 import time
 
 import numpy as np
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avisynth_sangnom2_amd import SangNom2, clip_format, synth, pin_host_array, unpin_host_array
 
 ap = argparse.ArgumentParser()
