@@ -412,6 +412,43 @@ def test_fused_420_hand_off_rows_match_the_shared_pool(hip_lib, fmt, w, h):
                 assert far.any() and not got[:, far].any()
 
 
+# Stage 2 of the pool path picks its kernel by sample type, pool stride and frames per launch (sn_pool_kernels.hip):
+# strips of 60 lanes x 8 columns from 512 columns on (float: launches of up to eight frames), eight columns per thread
+# below / otherwise.  Widths: 512 (two lanes in the second strip), 736 (a 720-wide clip's stride is the same: second
+# strip partly idle), 1000 (stride 1024: three strips), 1504 (four strips), 480 (below the strips).
+STAGE2_WIDTHS = (480, 512, 736, 1000, 1504)
+
+
+@pytest.mark.parametrize("w", STAGE2_WIDTHS)
+@pytest.mark.parametrize("fmt", ["Y8", "Y12", "Y16", "Y32"])
+def test_pool_stage2_kernels_match_oracle(hip_lib, fmt, w):
+    import torch
+    clip = clip_format(fmt, w, 56)
+    kw = dict(aa=48)
+    history_free = w % 32 == 0
+    N = 10
+    frames = make_frames(clip, "noise", N - 1, seed0=11) + [synth.frame(clip, "checker", seed=1)]
+    dev = torch.device("cuda:0")
+    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
+    vdt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+    ora = Oracle(oracle_cfg(clip, **kw))
+    want = [ora.process(fr, parity=1) for fr in frames]
+    with SangNom2(clip, max_batch=N, mode="pool", **kw) as flt:
+        assert bool(flt.info().history_free) == history_free
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames]).view(vdt)).to(dev)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(0), dtype=tdt, device=dev)]
+        # one launch of three frames and one of ten; a history-carrying clip (1000 wide) runs frame by frame whatever
+        # the launch holds, and its frames must come in the oracle's order from a new instance
+        for n in ((3, N) if history_free else (N,)):
+            dst[0].zero_()
+            torch.cuda.synchronize()
+            flt.process_batch([src[0][:n]], [dst[0][:n]], parity=[1] * n)
+            flt.synchronize()
+            for f in range(n):
+                got = dst[0][f].cpu().numpy().view(clip.dtype)
+                assert same(want[f][0], got), f"{fmt} {w} launch of {n}, frame {f}: " + describe_diff(want[f][0], got)
+
+
 @pytest.mark.parametrize("fmt,mode", [("YUV420P8", "fused"), ("YUV420P16", "fused"), ("YUV420P8", "pool"), ("Y16", "pool")])
 def test_batch_larger_than_the_scratch_budget_runs_in_chunks(hip_lib, monkeypatch, fmt, mode):
     """Scratch is bounded (SN_SCRATCH_BUDGET_MB): a bigger batch is run in chunks on the same slots."""
