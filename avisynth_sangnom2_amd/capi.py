@@ -42,7 +42,8 @@ class SnInfo(ctypes.Structure):
                 ("frames", ctypes.c_int64), ("fused_frames", ctypes.c_int64),
                 ("coupled_rows", ctypes.c_int32), ("reserved0", ctypes.c_int32),
                 ("threshold", ctypes.c_double * 3),
-                ("banded_frames", ctypes.c_int64), ("band_fallbacks", ctypes.c_int64)]
+                ("banded_frames", ctypes.c_int64), ("band_fallbacks", ctypes.c_int64),
+                ("chained_frames", ctypes.c_int64)]
 
 
 def build(force: bool = False) -> str:

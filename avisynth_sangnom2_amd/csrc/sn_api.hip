@@ -106,6 +106,10 @@ struct Context {
     // row-band sweeps of small launches (sn_fused_v3_common.h): per scratch slot the bands' state
     // snapshots and the frame's flag; the verification counts failed frames in band_fallbacks_dev and mirrors the count
     // into band_fallbacks, host memory the device can write (what the pause heuristic of band_count looks at)
+    // the chain of a history-carrying stream (run_chain): a ring of pool slots, one per pass in flight
+    uint8_t* chain_base = nullptr;
+    int chain_slots = 0, chain_origin = 0;
+    int64_t chained_frames = 0;
     uint32_t* band_state = nullptr;
     int32_t* band_flags = nullptr;
     int64_t* band_fallbacks = nullptr;
@@ -289,6 +293,7 @@ void sn_destroy(sn_context* h)
     for (auto& g : c->ring)
         if (g.stream) (void)hipStreamSynchronize(g.stream);
     if (c->pool.base) (void)hipFree(c->pool.base);
+    if (c->chain_base) (void)hipFree(c->chain_base);
     for (int p = 0; p < 3; ++p)
         if (c->plane_pool[p].base) (void)hipFree(c->plane_pool[p].base);
     for (int i = 0; i < 2; ++i)
@@ -995,18 +1000,114 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     return SN_OK;
 }
 
+// History-carrying clips, several frames of one field offset: the reference's passes -- every processed plane of every
+// frame, in order, each starting from the pool the pass before it left -- as ONE chain (sn_pool_kernels.hip,
+// k_smooth_u8_chain): stage 1 of all passes into a slot each, one stage-2 launch that keeps several passes in
+// flight, stage 3 of all passes.  The pool of slot 0 is where the chain starts and where its last pass's pool ends
+// up, so frames that come one at a time (and the pool's readers) carry on from there.
+static int chain_planes(const Context* c, int planes[3])
+{
+    if (c->history_free || c->isolated || c->gate.on || c->cfg.mode == SN_MODE_FUSED) return 0;
+    if (sn::pool_chain_lanes(c->cfg.bytes_per_sample, c->stride_e) < 2 || c->bh < 2) return 0;
+    if (const char* e = getenv("SN_CHAIN"))
+        if (atoi(e) == 0) return 0;
+    int pn = 0;
+    for (int p = 0; p < c->nplanes(); ++p) {
+        if (!(c->cfg.dh || c->process[p])) continue;
+        if (c->plane_w(p) % 8 != 0 || c->plane_h_out(p) / 2 - 1 >= c->bh || c->plane_h_out(p) / 2 - 1 < 1) return 0;
+        planes[pn++] = p;
+    }
+    return pn;
+}
+
+static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3], const int64_t sfs[3], const int32_t sp[3],
+                     void* const dst[3], const int64_t dfs[3], const int32_t dp[3], int f0, int offset, const int planes[3], int pn)
+{
+    int rc = ensure_pool(c);
+    if (rc != SN_OK) return rc;
+    const int B = c->cfg.bytes_per_sample;
+    if (!c->chain_base) {
+        int64_t fit = scratch_budget() / 8 / c->pool.slot_bytes;  // passes per launch
+        const int64_t want = (int64_t)c->cfg.max_batch * pn;
+        fit = fit > want ? want : fit;
+        fit = fit > 1536 ? 1536 : fit;
+        if (fit < 2 * pn) fit = 2 * pn;
+        c->chain_slots = (int)fit + 1;
+        SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chain_base), (size_t)c->pool.slot_bytes * c->chain_slots));
+        SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
+        c->chain_origin = 0;
+    }
+    sn::PlaneArgs pa[3];
+    for (int p = 0; p < c->nplanes(); ++p) {
+        sn::PlaneArgs& a = pa[p];
+        a = sn::PlaneArgs{};
+        a.src = static_cast<const uint8_t*>(src[p]) + (int64_t)f0 * sfs[p];
+        a.dst = static_cast<uint8_t*>(dst[p]) + (int64_t)f0 * dfs[p];
+        a.src_frame_stride = sfs[p];
+        a.dst_frame_stride = dfs[p];
+        a.src_pitch = sp[p];
+        a.dst_pitch = dp[p];
+        a.w = c->plane_w(p);
+        a.h_in = c->plane_h_in(p);
+        a.h_out = c->plane_h_out(p);
+        a.offset = offset;
+        a.dh = c->cfg.dh;
+        a.enabled = (c->cfg.dh || c->process[p]) ? 1 : 0;
+        SN_HIP(c, sn::launch_assemble(st, a, B, n));
+    }
+    sn::PoolArgs ring = c->pool;
+    ring.base = c->chain_base;
+    ring.rows = 0;
+    ring.guard = nullptr;
+    ring.slot_step = pn;
+    ring.slot_mod = c->chain_slots;
+    const int per_launch = (c->chain_slots - 1) / pn;  // frames
+    for (int i = 0; i < n; i += per_launch) {
+        const int m = n - i < per_launch ? n - i : per_launch;
+        uint8_t* first = c->chain_base + (int64_t)c->chain_origin * c->pool.slot_bytes;
+        SN_HIP(c, hipMemcpyAsync(first, c->pool.base, (size_t)c->pool.slot_bytes, hipMemcpyDeviceToDevice, st));
+        sn::ChainArgs ch{};
+        ch.npass = m * pn;
+        ch.pn = pn;
+        ch.origin = c->chain_origin;
+        for (int k = 0; k < pn; ++k) {
+            sn::PlaneArgs a = pa[planes[k]];
+            a.src += (int64_t)i * a.src_frame_stride;
+            a.dst += (int64_t)i * a.dst_frame_stride;
+            ch.w[k] = a.w;
+            ch.nr[k] = a.h_out / 2 - 1;
+            SN_HIP(c, sn::launch_pool_prepare(st, a, ring, B, m, (c->chain_origin + 1 + k) % c->chain_slots));
+        }
+        SN_HIP(c, sn::launch_pool_chain(st, ring, ch, B));
+        for (int k = 0; k < pn; ++k) {
+            sn::PlaneArgs a = pa[planes[k]];
+            a.src += (int64_t)i * a.src_frame_stride;
+            a.dst += (int64_t)i * a.dst_frame_stride;
+            SN_HIP(c, sn::launch_pool_finalize(st, a, ring, B, c->threshold(planes[k]), m, (c->chain_origin + 1 + k) % c->chain_slots));
+        }
+        c->chain_origin = (c->chain_origin + ch.npass) % c->chain_slots;
+        const uint8_t* last = c->chain_base + (int64_t)c->chain_origin * c->pool.slot_bytes;
+        SN_HIP(c, hipMemcpyAsync(c->pool.base, last, (size_t)c->pool.slot_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    c->chained_frames += n;
+    return SN_OK;
+}
+
 // Splits a batch into runs of equal field offset; history-carrying configurations run one frame at a time on
-// pool slot 0, exactly like one reference instance.
+// pool slot 0, exactly like one reference instance -- or, several frames of one offset, as a chain (run_chain).
 static int run_batch(Context* c, hipStream_t st, int slot0, int nframes, const void* const src[3], const int64_t sfs[3],
                      const int32_t sp[3], void* const dst[3], const int64_t dfs[3], const int32_t dp[3], const int32_t* parity)
 {
     int f = 0;
+    int planes[3] = {0, 0, 0};
+    const int pn = slot0 == 0 ? chain_planes(c, planes) : 0;
     while (f < nframes) {
         const int off = field_offset(c, parity ? parity[f] : 1);
         int g = f + 1;
-        if (c->history_free)
+        if (c->history_free || pn)
             while (g < nframes && field_offset(c, parity ? parity[g] : 1) == off) ++g;
-        const int rc = run_group(c, st, slot0, g - f, src, sfs, sp, dst, dfs, dp, f, off);
+        const int rc = !c->history_free && g - f > 1 ? run_chain(c, st, g - f, src, sfs, sp, dst, dfs, dp, f, off, planes, pn)
+                                                     : run_group(c, st, slot0, g - f, src, sfs, sp, dst, dfs, dp, f, off);
         if (rc != SN_OK) return rc;
         f = g;
     }
@@ -1451,6 +1552,7 @@ int sn_get_info(sn_context* h, sn_info* info)
     info->coupled_rows = c->fused420 ? c->fpool_rows : 0;
     info->reserved0 = 0;
     info->banded_frames = c->banded_frames;
+    info->chained_frames = c->chained_frames;
     info->band_fallbacks = 0;
     if (c->band_fallbacks_dev) {  // the device's own count (the host mirror may lag behind a launch with several failing frames)
         SN_HIP(c, hipSetDevice(c->device));

@@ -36,6 +36,17 @@ struct PoolArgs {
     int32_t bh;                // bufferHeight; a buffer has bh + 1 rows
     const int32_t* guard;      // as PlaneArgs::guard
     int32_t rows;              // stage 2 stops before this pool row (0 = bh: the whole pool, as the reference does)
+    int32_t slot_step = 0;     // k_prepare / k_finalize: frame f uses slot (slot0 + f * slot_step) % slot_mod
+    int32_t slot_mod = 0;      // (0 / 0: slot0 + f)
+};
+
+// Stage 2 of a history-carrying clip as a chain of passes (one per processed plane and frame, in the reference's
+// order): pass j smooths slot (origin + 1 + j) % slot_mod and takes every cell its own k_prepare did not write --
+// columns from w[j % pn] on, rows above nr[j % pn], row 0 -- from the slot of the pass before it.
+struct ChainArgs {
+    int32_t npass, pn;
+    int32_t w[3], nr[3];
+    int32_t origin;
 };
 
 struct Context;
@@ -48,6 +59,11 @@ hipError_t launch_turn(hipStream_t s, int bytes, int right, int nframes, const u
 hipError_t launch_assemble(hipStream_t s, const PlaneArgs& p, int bytes, int nframes);
 hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes,
                              double threshold, int nframes, int slot0);
+int pool_chain_lanes(int bytes, int stride_e);  // passes one workgroup keeps in flight; 0: no chain for this pool
+hipError_t launch_pool_prepare(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes, int nframes, int slot0);
+hipError_t launch_pool_finalize(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes, double threshold, int nframes,
+                                int slot0);
+hipError_t launch_pool_chain(hipStream_t s, const PoolArgs& pool, const ChainArgs& chain, int bytes);
 
 // sn_fused_select.hip: which configurations the fused sweeps serve.  A fused launch also does the plane's frame
 // assembly, so launch_assemble must not be called for a plane it serves.

@@ -104,6 +104,12 @@ struct Taps {
 // ------------------------------------------------------------------------------------------------
 // Stage 1: prepareBuffers_c, SangNom2.cpp:74-124.  One thread per pixel of one line pair.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t slot_of(const PoolArgs& pool, int slot0, int f)
+{
+    const int s = slot0 + f * (pool.slot_step ? pool.slot_step : 1);
+    return pool.slot_mod ? s % pool.slot_mod : s;
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) k_prepare(PlaneArgs p, PoolArgs pool, int slot0)
 {
@@ -118,7 +124,7 @@ __global__ void __launch_bounds__(256) k_prepare(PlaneArgs p, PoolArgs pool, int
     const T* nl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y + 2) * p.dst_pitch);
     Taps<T> t;
     t.load(cl, nl, x, p.w);
-    T* pb = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes);
+    T* pb = reinterpret_cast<T*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes);
     const size_t bufsz = (size_t)pool.stride_e * (pool.bh + 1);
     const size_t at = (size_t)(y + 1) * pool.stride_e + x;
     pb[0 * bufsz + at] = (T)P::adiff(t.c[0], t.n[6]);  // ADIFF_M3_P3
@@ -411,6 +417,146 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs po
                 ring[u] = load(row_or_last(r + u + 2 + kAhead));
                 row_step(r + u, pre);
             }
+        }
+    }
+}
+
+// History-carrying 8-bit clips (pool cells a pass does not write keep what the pass before it left): the
+// passes of a stream form a chain, but pass j + 1 only needs rows r + 1, r + 2 of what pass j smoothed, so one
+// persistent workgroup per buffer keeps `lanes` passes in flight, each on the nw waves of a strip set
+// (k_smooth_u8_strips), each kLag blocks of K rows behind the one before it.  Every pass has a pool slot of its own
+// (ChainArgs); a lane reads a raw row from its own slot where its pass's k_prepare wrote it and from the slot of the
+// pass before it everywhere else.  All waves meet at one barrier per block -- the one the strips need anyway for their
+// ghost lanes -- which is also what orders pass j's stores before pass j + 1's loads (same workgroup, same CU), so
+// nothing ever waits on another workgroup.  A pass: one round that fetches its first rows, then ceil((bh - 1) / K)
+// blocks; block t of a pass fetches up to row K (t + 2) + 2 of the pass before it, which finished that block one
+// round earlier when the lag is three rounds.
+constexpr int kChainLag = 3;
+
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
+                                                                    int cycle)
+{
+    using namespace v3c;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;
+    const int nl = se >> 3;  // lanes that own columns
+    const int b = blockIdx.x;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ps = (tid >> 6) / nw, wave = (tid >> 6) % nw;  // which pass of the `lanes` in flight, which strip of it
+    int gl;
+    bool ghost;
+    if (wave == 0) {
+        gl = lane;
+        ghost = nw > 1 && lane >= 64 - GH;
+    } else {
+        gl = kFirst + kInner * (wave - 1) + (lane - GH);
+        ghost = lane < GH || (lane >= 64 - GH && wave < nw - 1);
+    }
+    const bool live = gl < nl, real = live && !ghost;
+    const int x0 = live ? gl * 8 : 0;  // dead lanes shadow column 0 and store nothing
+    const unsigned first_mask = live && gl == 0 ? 0xffffffffu : 0u, last_mask = live && gl == nl - 1 ? 0xffffffffu : 0u;
+    // mailbox: [pass in flight][copy][wave][side][slot][4 registers]
+    unsigned* mb = reinterpret_cast<unsigned*>(smem) + (size_t)ps * (2 * nw * 2 * GH * 4);
+    auto mb_at = [&](int copy, int w, int side, int slot) { return mb + ((((copy * nw + w) * 2 + side) * GH + slot) * 4); };
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < nw - 1;
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    struct Row {
+        unsigned v[4];  // columns x0 + 2i | x0 + 2i + 1 << 16
+    };
+    auto unpack = [](uint2 q) {
+        Row r;
+        r.v[0] = __builtin_amdgcn_perm(0u, q.x, 0x0c010c00u);
+        r.v[1] = __builtin_amdgcn_perm(0u, q.x, 0x0c030c02u);
+        r.v[2] = __builtin_amdgcn_perm(0u, q.y, 0x0c010c00u);
+        r.v[3] = __builtin_amdgcn_perm(0u, q.y, 0x0c030c02u);
+        return r;
+    };
+    const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int ncycles = (ch.npass + lanes - 1) / lanes;
+    const int total = (ncycles - 1) * cycle + (lanes - 1) * kChainLag + pass_rounds;
+
+    // state of the pass this wave is working on
+    const uint8_t* own = nullptr;   // this lane's columns in the pass's slot ...
+    const uint8_t* before = nullptr;  // ... and in the slot of the pass before it
+    uint8_t* out = nullptr;
+    int fresh_rows = 0;  // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
+    Row prev{}, cur{}, nxt{};
+    constexpr int kAhead = K;
+    uint2 ring[kAhead] = {};
+    auto load = [&](int row) {
+        row = row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
+        const uint8_t* from = row >= 1 && row <= fresh_rows ? own : before;
+        return *reinterpret_cast<const uint2*>(from + (size_t)row * se);
+    };
+
+    for (int round = 0; round < total; ++round) {
+        __syncthreads();
+        const int rel = round - ps * kChainLag;
+        if (rel < 0) continue;
+        const int j = (rel / cycle) * lanes + ps, t = rel % cycle - 1;
+        if (j >= ch.npass || t >= pass_rounds - 1) continue;
+        if (t < 0) {  // the pass's first rows
+            const int k = j % ch.pn;
+            const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
+            own = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
+            before = pool.base + s_before * pool.slot_bytes + (size_t)b * bufsz + x0;
+            out = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
+            fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
+            prev = unpack(load(0));
+            cur = unpack(load(1));
+            nxt = unpack(load(2));
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) ring[u] = load(3 + u);
+            continue;
+        }
+        if (t > 0 && recv) {  // the ghosts take over what the seam lanes held after the block before
+            const unsigned* from = mb_at(t & 1, wave, lane < GH ? 0 : 1, slot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) prev.v[i] = from[i];
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int r = K * t + 1 + u;
+            if (r < rows) {  // uniform
+                const uint2 pre = ring[u];
+                ring[u] = load(r + 2 + kAhead);
+                unsigned E[8];  // as k_smooth_u8_strips
+#pragma unroll
+                for (int i = 0; i < 4; ++i) E[2 + i] = prev.v[i] + cur.v[i] + nxt.v[i];
+                const unsigned left_edge = (E[2] & 0xffffu) * 0x10001u, right_edge = (E[5] >> 16) * 0x10001u;
+                E[0] = (first_mask & left_edge) | (~first_mask & dpp_from_left(E[4]));
+                E[1] = (first_mask & left_edge) | (~first_mask & dpp_from_left(E[5]));
+                E[6] = (last_mask & right_edge) | (~last_mask & dpp_from_right(E[2]));
+                E[7] = (last_mask & right_edge) | (~last_mask & dpp_from_right(E[3]));
+                unsigned O[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) O[q] = __builtin_amdgcn_alignbit(E[q + 1], E[q], 16);
+                unsigned T = ((O[0] + E[1]) + (O[1] + E[2])) + ((O[2] + E[3]) + O[3]);
+                Row o;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    o.v[m] = (T >> 4) & 0x00ff00ffu;
+                    if (m < 3) T = (T - O[m] - E[1 + m]) + (E[4 + m] + O[m + 4]);
+                }
+                if (real) {
+                    uint2 q;
+                    q.x = __builtin_amdgcn_perm(o.v[1], o.v[0], 0x06040200u);
+                    q.y = __builtin_amdgcn_perm(o.v[3], o.v[2], 0x06040200u);
+                    *reinterpret_cast<uint2*>(out + (size_t)r * se) = q;
+                }
+                prev = o;
+                cur = nxt;
+                nxt = unpack(pre);
+            }
+        }
+        if (K * (t + 1) < rows - 1 && (pub_right || pub_left)) {
+            unsigned* to = pub_right ? mb_at((t + 1) & 1, wave + 1, 0, slot) : mb_at((t + 1) & 1, wave - 1, 1, slot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) to[i] = prev.v[i];
         }
     }
 }
@@ -904,7 +1050,7 @@ k_finalize(PlaneArgs p, PoolArgs pool, int slot0, typename Px<T>::W thr)
     T* ol = reinterpret_cast<T*>(plane + (int64_t)(p.offset + 2 * y + 1) * p.dst_pitch);
     Taps<T> t;
     t.load(cl, nl, x, p.w);
-    const T* pb = reinterpret_cast<const T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes);
+    const T* pb = reinterpret_cast<const T*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes);
     const size_t bufsz = (size_t)pool.stride_e * (pool.bh + 1);
     const size_t at = (size_t)(y + 1) * pool.stride_e + x;
     W v[9];
@@ -1000,6 +1146,69 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
         if constexpr (sizeof(T) == 4) thr = (float)threshold; else thr = (W)threshold;
         hipLaunchKernelGGL(k_finalize<T>, grid, block, 0, st, p, pool, slot0, thr);
     }
+    return hipGetLastError();
+}
+
+// ---- the chain of a history-carrying stream: stage 1 of all passes, one stage 2, stage 3 of all passes ----
+int pool_chain_lanes(int bytes, int stride_e)
+{
+    if (bytes != 1 || stride_e < 64) return 0;
+    const int nw = v3c::strips_for(stride_e / 8);
+    return nw <= kSmoothThreads / 128 ? kSmoothThreads / 64 / nw : 0;  // at least two passes in flight
+}
+
+template <class T>
+static hipError_t launch_pool_prepare_t(hipStream_t st, const PlaneArgs& p, const PoolArgs& pool, int nframes, int slot0)
+{
+    const int nr = p.h_out / 2 - 1;
+    if (nr > 0) hipLaunchKernelGGL(k_prepare<T>, dim3((p.w + 255) / 256, nr, nframes), dim3(256), 0, st, p, pool, slot0);
+    return hipGetLastError();
+}
+
+template <class T>
+static hipError_t launch_pool_finalize_t(hipStream_t st, const PlaneArgs& p, const PoolArgs& pool, double threshold, int nframes,
+                                         int slot0)
+{
+    using W = typename Px<T>::W;
+    const int nr = p.h_out / 2 - 1;
+    W thr;
+    if constexpr (sizeof(T) == 4) thr = (float)threshold; else thr = (W)threshold;
+    if (nr > 0) hipLaunchKernelGGL(k_finalize<T>, dim3((p.w + 255) / 256, nr, nframes), dim3(256), 0, st, p, pool, slot0, thr);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_prepare(hipStream_t st, const PlaneArgs& p, const PoolArgs& pool, int bytes, int nframes, int slot0)
+{
+    switch (bytes) {
+    case 1: return launch_pool_prepare_t<uint8_t>(st, p, pool, nframes, slot0);
+    case 2: return launch_pool_prepare_t<uint16_t>(st, p, pool, nframes, slot0);
+    case 4: return launch_pool_prepare_t<float>(st, p, pool, nframes, slot0);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_pool_finalize(hipStream_t st, const PlaneArgs& p, const PoolArgs& pool, int bytes, double threshold, int nframes,
+                                int slot0)
+{
+    switch (bytes) {
+    case 1: return launch_pool_finalize_t<uint8_t>(st, p, pool, threshold, nframes, slot0);
+    case 2: return launch_pool_finalize_t<uint16_t>(st, p, pool, threshold, nframes, slot0);
+    case 4: return launch_pool_finalize_t<float>(st, p, pool, threshold, nframes, slot0);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainArgs& chain, int bytes)
+{
+    const int lanes = pool_chain_lanes(bytes, pool.stride_e);
+    if (lanes < 2 || pool.slot_mod <= chain.npass || chain.npass < 1 || pool.bh < 2) return hipErrorInvalidValue;
+    for (int k = 0; k < chain.pn; ++k)
+        if (chain.w[k] % 8 != 0 || chain.nr[k] >= pool.bh) return hipErrorInvalidValue;
+    const int nw = v3c::strips_for(pool.stride_e / 8);
+    const int pass_rounds = 1 + (pool.bh - 1 + v3c::K - 1) / v3c::K;
+    const int cycle = pass_rounds > lanes * kChainLag ? pass_rounds : lanes * kChainLag;
+    const size_t lds = (size_t)lanes * 2 * nw * 2 * v3c::GH * 4 * sizeof(unsigned);
+    hipLaunchKernelGGL(k_smooth_u8_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     return hipGetLastError();
 }
 

@@ -449,6 +449,70 @@ def test_pool_stage2_kernels_match_oracle(hip_lib, fmt, w):
                 assert same(want[f][0], got), f"{fmt} {w} launch of {n}, frame {f}: " + describe_diff(want[f][0], got)
 
 
+# History-carrying 8-bit clips, several frames per launch: the passes run as one chain (run_chain, k_smooth_u8_chain).
+CHAIN_CASES = [
+    # fmt, w, h, kw, frames, SN_SCRATCH_BUDGET_MB
+    ("YUV420P8", 720, 96, dict(aac=48), 12, None),              # two strips, eight passes in flight, three planes a frame
+    ("Y8", 1000, 56, dict(aa=20), 10, None),                     # three strips
+    ("Y8", 40, 200, dict(order=0), 7, None),                     # one strip, sixteen passes in flight; the field follows the parity
+    ("YUV420P8", 128, 64, dict(luma=False, aac=33), 20, None),   # chroma only: a multiple of 32 wide and still a chain
+    ("YUV420P8", 128, 64, dict(luma=False, aac=33), 20, 1),      # ... in launches of a few passes
+    ("YUV422P8", 208, 48, dict(aac=48, dh=True), 9, None),
+    ("YUV420P8", 1456, 40, dict(aac=10), 6, None),               # four strips, four passes in flight
+]
+
+
+@pytest.mark.parametrize("fmt,w,h,kw,N,budget", CHAIN_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}-{i}" for i, c in enumerate(CHAIN_CASES)])
+@pytest.mark.parametrize("mode", ["auto", "pool"])
+def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, kw, N, budget, mode):
+    import torch
+    if budget:
+        monkeypatch.setenv("SN_SCRATCH_BUDGET_MB", str(budget))
+    clip = clip_format(fmt, w, h)
+    frames = make_frames(clip, "noise", N - 1, seed0=5) + [synth.frame(clip, "checker", seed=2)]
+    parity = [1] * (N // 2) + [0] + [1] * (N - N // 2 - 1)  # two chains with a single frame of the other field between them
+    ora = Oracle(oracle_cfg(clip, **kw))
+    dev = torch.device("cuda:0")
+    with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
+        assert not flt.info().history_free
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).to(dev) for p in range(clip.planes)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(clip.planes)]
+        torch.cuda.synchronize()
+        for rnd in range(2):  # the second launch starts from the pool the first one left
+            flt.process_batch(src, dst, parity=parity)
+            flt.synchronize()
+            for f in range(N):
+                want = ora.process(frames[f], parity=parity[f])
+                for p in range(clip.planes):
+                    got = dst[p][f].cpu().numpy()
+                    assert same(want[p], got), f"round {rnd} frame {f} plane {p}: " + describe_diff(want[p], got)
+        assert 2 * (N - 1) <= flt.info().chained_frames <= 2 * N  # (the field only moves the lines when order = 0)
+        # a frame on its own carries on from the chain's last pool, and the pool itself is the reference's
+        want = ora.process(frames[0], parity=1)
+        got = flt.get_frame(frames[0], parity=1)
+        for p in range(clip.planes):
+            assert same(want[p], got[p]), f"single frame after the chains, plane {p}: " + describe_diff(want[p], got[p])
+        assert np.array_equal(ora.pool(), flt.read_pool(0))
+
+
+def test_chain_can_be_switched_off(hip_lib, monkeypatch):
+    import torch
+    monkeypatch.setenv("SN_CHAIN", "0")
+    clip = clip_format("Y8", 1000, 56)
+    frames = make_frames(clip, "noise", 4, seed0=5)
+    ora = Oracle(oracle_cfg(clip))
+    dev = torch.device("cuda:0")
+    with SangNom2(clip, max_batch=4) as flt:
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).to(dev)]
+        dst = [torch.zeros((4,) + flt.plane_shape_out(0), dtype=torch.uint8, device=dev)]
+        torch.cuda.synchronize()
+        flt.process_batch(src, dst)
+        flt.synchronize()
+        assert flt.info().chained_frames == 0
+        for f in range(4):
+            assert same(ora.process(frames[f])[0], dst[0][f].cpu().numpy())
+
+
 @pytest.mark.parametrize("fmt,mode", [("YUV420P8", "fused"), ("YUV420P16", "fused"), ("YUV420P8", "pool"), ("Y16", "pool")])
 def test_batch_larger_than_the_scratch_budget_runs_in_chunks(hip_lib, monkeypatch, fmt, mode):
     """Scratch is bounded (SN_SCRATCH_BUDGET_MB): a bigger batch is run in chunks on the same slots."""
