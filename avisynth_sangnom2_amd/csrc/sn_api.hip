@@ -1028,7 +1028,7 @@ static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3]
     const int B = c->cfg.bytes_per_sample;
     if (!c->chain_base) {
         int64_t fit = scratch_budget() / 8 / c->pool.slot_bytes;  // passes per launch
-        const int64_t want = (int64_t)c->cfg.max_batch * pn;
+        const int64_t want = (int64_t)(c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth) * pn;
         fit = fit > want ? want : fit;
         fit = fit > 1536 ? 1536 : fit;
         if (fit < 2 * pn) fit = 2 * pn;

@@ -495,6 +495,29 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
         assert np.array_equal(ora.pool(), flt.read_pool(0))
 
 
+def test_host_ring_groups_of_a_history_carrying_clip_run_as_chains(hip_lib):
+    """sn_submit_host / sn_collect_host with a ring deep enough for groups of several frames: a group's launch is a chain."""
+    clip = clip_format("YUV420P8", 720, 64)
+    kw = dict(aac=48)
+    N = 21
+    frames = make_frames(clip, "noise", N, seed0=9)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    with SangNom2(clip, host_depth=12, **kw) as flt:
+        slots = flt.host_slots()
+        got, inflight = [], []
+        for f in range(N):
+            if len(inflight) == slots:
+                got.append(flt.collect(inflight.pop(0)))
+            inflight.append(flt.submit(frames[f]))
+        while inflight:
+            got.append(flt.collect(inflight.pop(0)))
+        assert flt.info().chained_frames >= N // 2
+    for f in range(N):
+        want = ora.process(frames[f])
+        for p in range(clip.planes):
+            assert same(want[p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[p], got[f][p])
+
+
 def test_chain_can_be_switched_off(hip_lib, monkeypatch):
     import torch
     monkeypatch.setenv("SN_CHAIN", "0")

@@ -32,7 +32,7 @@ def main():
     rng = random.Random(a.seed)
     t_end = time.time() + a.seconds
     n = bad = 0
-    stats = {"fused": 0, "pool": 0, "ring": 0, "host": 0, "frames": 0, "pixels": 0, "banded_frames": 0, "band_fallbacks": 0}
+    stats = {"fused": 0, "pool": 0, "ring": 0, "host": 0, "batch": 0, "frames": 0, "pixels": 0, "banded_frames": 0, "band_fallbacks": 0, "chained_frames": 0}
     while time.time() < t_end:
         fmt = rng.choice(FORMATS)
         wide = rng.random() < 0.15
@@ -57,7 +57,8 @@ def main():
         kw = dict(order=rng.randint(0, 2), aa=rng.choice([0, 1, 20, 48, 100, 128]), aac=rng.choice([0, 48, 128]),
                   dh=rng.random() < 0.2, luma=rng.random() < 0.85, chroma=rng.random() < 0.8)
         ext = rng.choice(["none", "none", "isolated", "fresh"])
-        nframes = rng.randint(1, 4)
+        way = rng.choice(["host", "ring", "batch"])  # batch: device-resident frames, one launch (history-carrying 8-bit clips: the chain)
+        nframes = rng.randint(1, 4) if way != "batch" else rng.randint(2, 10)
         pattern = rng.choice(["noise", "noise", "checker", "edges", "sine"])
         frames = [synth.frame(clip, pattern, seed=rng.randint(0, 1 << 20)) for _ in range(nframes)]
         parity = [rng.randint(0, 1) for _ in range(nframes)]
@@ -78,10 +79,9 @@ def main():
                     o = mk() if ext == "fresh" else per_plane.setdefault(p, mk())
                     outs.append(o.process([pl], parity=parity[f])[0])
                 want.append(outs)
-        way = rng.choice(["host", "ring"])
         os.environ["SN_PREFER_POOL"] = rng.choice(["0", "1"])  # the whole-plane sweeps, or auto mode's small-launch paths (bands, pool kernels)
         try:
-            flt = SangNom2(clip, host_depth=rng.randint(1, 5), isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", **kw)
+            flt = SangNom2(clip, host_depth=rng.choice([1, 2, 3, 4, 5, 8, 12]), max_batch=nframes, isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", **kw)
         except Exception as e:  # a geometry the library rejects must be one it documents
             if "exceeds the supported maximum" in str(e):
                 continue
@@ -98,6 +98,16 @@ def main():
             stats["pixels"] += nframes * w * h
             if way == "host":
                 got = [flt.get_frame(frames[f], parity=parity[f]) for f in range(nframes)]
+            elif way == "batch":
+                import torch
+                dev = torch.device("cuda:0")
+                view = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+                src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).to(dev) for p in range(clip.planes)]
+                dst = [torch.zeros((nframes,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(clip.planes)]
+                torch.cuda.synchronize()
+                flt.process_batch(src, dst, parity=parity)
+                flt.synchronize()
+                got = [[dst[p][f].cpu().numpy().view(clip.dtype) for p in range(clip.planes)] for f in range(nframes)]
             else:
                 slots = flt.host_slots()
                 inflight = []
@@ -111,6 +121,7 @@ def main():
             fused = info.fused_frames > 0
             stats["banded_frames"] += info.banded_frames
             stats["band_fallbacks"] += info.band_fallbacks
+            stats["chained_frames"] += info.chained_frames
         stats["fused" if fused else "pool"] += 1
         for f in range(nframes):
             for p in range(clip.planes):
