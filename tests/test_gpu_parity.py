@@ -449,7 +449,8 @@ def test_pool_stage2_kernels_match_oracle(hip_lib, fmt, w):
                 assert same(want[f][0], got), f"{fmt} {w} launch of {n}, frame {f}: " + describe_diff(want[f][0], got)
 
 
-# History-carrying 8-bit clips, several frames per launch: the passes run as one chain (run_chain, k_smooth_u8_chain).
+# History-carrying integer clips, several frames per launch: the passes run as one chain (run_chain, k_smooth_u8_chain /
+# k_smooth_u16_chain).
 CHAIN_CASES = [
     # fmt, w, h, kw, frames, SN_SCRATCH_BUDGET_MB
     ("YUV420P8", 720, 96, dict(aac=48), 12, None),              # two strips, eight passes in flight, three planes a frame
@@ -459,6 +460,10 @@ CHAIN_CASES = [
     ("YUV420P8", 128, 64, dict(luma=False, aac=33), 20, 1),      # ... in launches of a few passes
     ("YUV422P8", 208, 48, dict(aac=48, dh=True), 9, None),
     ("YUV420P8", 1456, 40, dict(aac=10), 6, None),               # four strips, four passes in flight
+    ("YUV420P10", 720, 96, dict(aac=48), 12, None),              # 9..16-bit samples: k_smooth_u16_chain
+    ("Y16", 1000, 56, dict(aa=20), 10, None),
+    ("YUV420P16", 128, 64, dict(luma=False, aac=33), 20, 1),
+    ("Y12", 40, 200, dict(order=0), 7, None),
 ]
 
 
@@ -475,8 +480,9 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
     dev = torch.device("cuda:0")
     with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
         assert not flt.info().history_free
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).to(dev) for p in range(clip.planes)]
-        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(clip.planes)]
+        view = np.uint8 if clip.bytes == 1 else np.int16
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).to(dev) for p in range(clip.planes)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
         for rnd in range(2):  # the second launch starts from the pool the first one left
             flt.process_batch(src, dst, parity=parity)
@@ -484,7 +490,7 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
             for f in range(N):
                 want = ora.process(frames[f], parity=parity[f])
                 for p in range(clip.planes):
-                    got = dst[p][f].cpu().numpy()
+                    got = dst[p][f].cpu().numpy().view(clip.dtype)
                     assert same(want[p], got), f"round {rnd} frame {f} plane {p}: " + describe_diff(want[p], got)
         assert 2 * (N - 1) <= flt.info().chained_frames <= 2 * N  # (the field only moves the lines when order = 0)
         # a frame on its own carries on from the chain's last pool, and the pool itself is the reference's
