@@ -690,6 +690,137 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
     }
 }
 
+// The chain for float samples: the same schedule around the row body of k_smooth_f32_strips (every sum in the
+// reference's order).
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
+                                                                    int cycle)
+{
+    using namespace v3c;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int se = pool.stride_e;
+    const int nl = se >> 3;  // lanes that own columns
+    const int b = blockIdx.x;
+    const size_t bufsz = (size_t)se * (pool.bh + 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ps = (tid >> 6) / nw, wave = (tid >> 6) % nw;  // which pass of the `lanes` in flight, which strip of it
+    int gl;
+    bool ghost;
+    if (wave == 0) {
+        gl = lane;
+        ghost = nw > 1 && lane >= 64 - GH;
+    } else {
+        gl = kFirst + kInner * (wave - 1) + (lane - GH);
+        ghost = lane < GH || (lane >= 64 - GH && wave < nw - 1);
+    }
+    const bool live = gl < nl, real = live && !ghost;
+    const int x0 = live ? gl * 8 : 0;  // dead lanes shadow column 0 and store nothing
+    const unsigned first_mask = live && gl == 0 ? 0xffffffffu : 0u, last_mask = live && gl == nl - 1 ? 0xffffffffu : 0u;
+    // mailbox: [pass in flight][copy][wave][side][slot][8 registers]
+    float* mb = reinterpret_cast<float*>(smem) + (size_t)ps * (2 * nw * 2 * GH * 8);
+    auto mb_at = [&](int copy, int w, int side, int slot) { return mb + ((((copy * nw + w) * 2 + side) * GH + slot) * 8); };
+    const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < nw - 1;
+    const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
+    const bool recv = ghost && live;
+    const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
+
+    struct Row {
+        float v[8];
+    };
+    struct Raw {
+        float4 lo, hi;
+    };
+    auto unpack = [](const Raw& q) {
+        Row r;
+        r.v[0] = q.lo.x; r.v[1] = q.lo.y; r.v[2] = q.lo.z; r.v[3] = q.lo.w;
+        r.v[4] = q.hi.x; r.v[5] = q.hi.y; r.v[6] = q.hi.z; r.v[7] = q.hi.w;
+        return r;
+    };
+    auto pick = [](unsigned mask, float edge, float other) {  // bitwise, as in k_smooth_u8_strips
+        return __uint_as_float((mask & __float_as_uint(edge)) | (~mask & __float_as_uint(other)));
+    };
+    const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int ncycles = (ch.npass + lanes - 1) / lanes;
+    const int total = (ncycles - 1) * cycle + (lanes - 1) * kChainLag + pass_rounds;
+
+    // state of the pass this wave is working on
+    const float* own = nullptr;   // this lane's columns in the pass's slot ...
+    const float* before = nullptr;  // ... and in the slot of the pass before it
+    float* out = nullptr;
+    int fresh_rows = 0;  // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
+    Row prev{}, cur{}, nxt{};
+    constexpr int kAhead = K;
+    Raw ring[kAhead] = {};
+    auto load = [&](int row) {
+        row = row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
+        const float4* from = reinterpret_cast<const float4*>((row >= 1 && row <= fresh_rows ? own : before) + (size_t)row * se);
+        Raw q;
+        q.lo = from[0];
+        q.hi = from[1];
+        return q;
+    };
+
+    for (int round = 0; round < total; ++round) {
+        __syncthreads();
+        const int rel = round - ps * kChainLag;
+        if (rel < 0) continue;
+        const int j = (rel / cycle) * lanes + ps, t = rel % cycle - 1;
+        if (j >= ch.npass || t >= pass_rounds - 1) continue;
+        if (t < 0) {  // the pass's first rows
+            const int k = j % ch.pn;
+            const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
+            own = reinterpret_cast<const float*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
+            before = reinterpret_cast<const float*>(pool.base + s_before * pool.slot_bytes) + (size_t)b * bufsz + x0;
+            out = reinterpret_cast<float*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
+            fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
+            prev = unpack(load(0));
+            cur = unpack(load(1));
+            nxt = unpack(load(2));
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) ring[u] = load(3 + u);
+            continue;
+        }
+        if (t > 0 && recv) {  // the ghosts take over what the seam lanes held after the block before
+            const float4* from = reinterpret_cast<const float4*>(mb_at(t & 1, wave, lane < GH ? 0 : 1, slot));
+            const float4 lo = from[0], hi = from[1];
+            prev.v[0] = lo.x; prev.v[1] = lo.y; prev.v[2] = lo.z; prev.v[3] = lo.w;
+            prev.v[4] = hi.x; prev.v[5] = hi.y; prev.v[6] = hi.z; prev.v[7] = hi.w;
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int r = K * t + 1 + u;
+            if (r < rows) {  // uniform
+                const Raw pre = ring[u];
+                ring[u] = load(r + 2 + kAhead);
+                float X[14];  // as k_smooth_f32_strips
+#pragma unroll
+                for (int i = 0; i < 8; ++i) X[3 + i] = (prev.v[i] + cur.v[i]) + nxt.v[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    X[i] = pick(first_mask, X[3], __uint_as_float(dpp_from_left(__float_as_uint(X[8 + i]))));
+                    X[11 + i] = pick(last_mask, X[10], __uint_as_float(dpp_from_right(__float_as_uint(X[3 + i]))));
+                }
+                Row o;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)  // left to right, SangNom2.cpp:152
+                    o.v[m] = ((((((X[m] + X[m + 1]) + X[m + 2]) + X[m + 3]) + X[m + 4]) + X[m + 5]) + X[m + 6]) * 0.0625f;
+                if (real) {
+                    float4* q = reinterpret_cast<float4*>(out + (size_t)r * se);
+                    q[0] = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
+                    q[1] = make_float4(o.v[4], o.v[5], o.v[6], o.v[7]);
+                }
+                prev = o;
+                cur = nxt;
+                nxt = unpack(pre);
+            }
+        }
+        if (K * (t + 1) < rows - 1 && (pub_right || pub_left)) {
+            float* to = pub_right ? mb_at((t + 1) & 1, wave + 1, 0, slot) : mb_at((t + 1) & 1, wave - 1, 1, slot);
+            reinterpret_cast<float4*>(to)[0] = make_float4(prev.v[0], prev.v[1], prev.v[2], prev.v[3]);
+            reinterpret_cast<float4*>(to)[1] = make_float4(prev.v[4], prev.v[5], prev.v[6], prev.v[7]);
+        }
+    }
+}
+
 // 9..16-bit pools: eight columns per thread as well, one 32-bit sum per register (seven 3-row sums of 16-bit samples need 21
 // bits), a sliding box (two instructions per further column instead of three three-operand adds), one 16-byte row
 // access and two 16-byte LDS reads per thread and row: 55 vector instructions per 8 columns against 79 per 4
@@ -1281,7 +1412,7 @@ static hipError_t launch_pool_plane_t(hipStream_t st, const PlaneArgs& p, const 
 // ---- the chain of a history-carrying stream: stage 1 of all passes, one stage 2, stage 3 of all passes ----
 int pool_chain_lanes(int bytes, int stride_e)
 {
-    if (bytes > 2 || stride_e < 64) return 0;
+    if (stride_e < 64) return 0;
     const int nw = v3c::strips_for(stride_e / 8);
     return nw <= kSmoothThreads / 128 ? kSmoothThreads / 64 / nw : 0;  // at least two passes in flight
 }
@@ -1336,8 +1467,10 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
     const int nw = v3c::strips_for(pool.stride_e / 8);
     const int pass_rounds = 1 + (pool.bh - 1 + v3c::K - 1) / v3c::K;
     const int cycle = pass_rounds > lanes * kChainLag ? pass_rounds : lanes * kChainLag;
-    const size_t lds = (size_t)lanes * 2 * nw * 2 * v3c::GH * (bytes == 2 ? 8 : 4) * sizeof(unsigned);
-    if (bytes == 2)
+    const size_t lds = (size_t)lanes * 2 * nw * 2 * v3c::GH * (bytes >= 2 ? 8 : 4) * sizeof(unsigned);
+    if (bytes == 4)
+        hipLaunchKernelGGL(k_smooth_f32_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+    else if (bytes == 2)
         hipLaunchKernelGGL(k_smooth_u16_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else
         hipLaunchKernelGGL(k_smooth_u8_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);

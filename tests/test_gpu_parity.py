@@ -449,8 +449,7 @@ def test_pool_stage2_kernels_match_oracle(hip_lib, fmt, w):
                 assert same(want[f][0], got), f"{fmt} {w} launch of {n}, frame {f}: " + describe_diff(want[f][0], got)
 
 
-# History-carrying integer clips, several frames per launch: the passes run as one chain (run_chain, k_smooth_u8_chain /
-# k_smooth_u16_chain).
+# History-carrying clips, several frames per launch: the passes run as one chain (run_chain, k_smooth_{u8,u16,f32}_chain).
 CHAIN_CASES = [
     # fmt, w, h, kw, frames, SN_SCRATCH_BUDGET_MB
     ("YUV420P8", 720, 96, dict(aac=48), 12, None),              # two strips, eight passes in flight, three planes a frame
@@ -464,6 +463,9 @@ CHAIN_CASES = [
     ("Y16", 1000, 56, dict(aa=20), 10, None),
     ("YUV420P16", 128, 64, dict(luma=False, aac=33), 20, 1),
     ("Y12", 40, 200, dict(order=0), 7, None),
+    ("YUV420PS", 720, 96, dict(aac=48), 12, None),               # float samples: k_smooth_f32_chain
+    ("Y32", 1000, 56, dict(aa=20), 10, None),
+    ("YUV420PS", 128, 64, dict(luma=False, aac=33), 20, 1),
 ]
 
 
@@ -480,7 +482,7 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
     dev = torch.device("cuda:0")
     with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
         assert not flt.info().history_free
-        view = np.uint8 if clip.bytes == 1 else np.int16
+        view = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
         src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).to(dev) for p in range(clip.planes)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
