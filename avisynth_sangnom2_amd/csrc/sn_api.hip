@@ -1005,8 +1005,11 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
 // k_smooth_u8_chain): stage 1 of all passes into a slot each, one stage-2 launch that keeps several passes in
 // flight, stage 3 of all passes.  The pool of slot 0 is where the chain starts and where its last pass's pool ends
 // up, so frames that come one at a time (and the pool's readers) carry on from there.
+constexpr int SN_CHAIN_UNAVAILABLE = -1000;  // internal: run_chain could not get its ring, run_batch falls back
+
 static int chain_planes(const Context* c, int planes[3])
 {
+    if (c->chain_slots < 0) return 0;
     if (c->history_free || c->isolated || c->gate.on || c->cfg.mode == SN_MODE_FUSED) return 0;
     if (sn::pool_chain_lanes(c->cfg.bytes_per_sample, c->stride_e) < 2 || c->bh < 2) return 0;
     if (const char* e = getenv("SN_CHAIN"))
@@ -1023,6 +1026,7 @@ static int chain_planes(const Context* c, int planes[3])
 static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3], const int64_t sfs[3], const int32_t sp[3],
                      void* const dst[3], const int64_t dfs[3], const int32_t dp[3], int f0, int offset, const int planes[3], int pn)
 {
+    if (c->chain_slots < 0) return SN_CHAIN_UNAVAILABLE;
     int rc = ensure_pool(c);
     if (rc != SN_OK) return rc;
     const int B = c->cfg.bytes_per_sample;
@@ -1033,7 +1037,12 @@ static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3]
         fit = fit > 1536 ? 1536 : fit;
         if (fit < 2 * pn) fit = 2 * pn;
         c->chain_slots = (int)fit + 1;
-        SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chain_base), (size_t)c->pool.slot_bytes * c->chain_slots));
+        if (hipMalloc(reinterpret_cast<void**>(&c->chain_base), (size_t)c->pool.slot_bytes * c->chain_slots) != hipSuccess) {
+            (void)hipGetLastError();  // no room for the ring: this context keeps the frame-by-frame path
+            c->chain_base = nullptr;
+            c->chain_slots = -1;
+            return SN_CHAIN_UNAVAILABLE;
+        }
         SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
         c->chain_origin = 0;
     }
@@ -1106,8 +1115,12 @@ static int run_batch(Context* c, hipStream_t st, int slot0, int nframes, const v
         int g = f + 1;
         if (c->history_free || pn)
             while (g < nframes && field_offset(c, parity ? parity[g] : 1) == off) ++g;
-        const int rc = !c->history_free && g - f > 1 ? run_chain(c, st, g - f, src, sfs, sp, dst, dfs, dp, f, off, planes, pn)
-                                                     : run_group(c, st, slot0, g - f, src, sfs, sp, dst, dfs, dp, f, off);
+        int rc = !c->history_free && g - f > 1 ? run_chain(c, st, g - f, src, sfs, sp, dst, dfs, dp, f, off, planes, pn)
+                                               : run_group(c, st, slot0, g - f, src, sfs, sp, dst, dfs, dp, f, off);
+        if (rc == SN_CHAIN_UNAVAILABLE) {  // nothing was queued yet: this frame and the rest one at a time
+            g = f + 1;
+            rc = run_group(c, st, slot0, 1, src, sfs, sp, dst, dfs, dp, f, off);
+        }
         if (rc != SN_OK) return rc;
         f = g;
     }
