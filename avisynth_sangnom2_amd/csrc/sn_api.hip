@@ -1010,7 +1010,7 @@ constexpr int SN_CHAIN_UNAVAILABLE = -1000;  // internal: run_chain could not ge
 static int chain_planes(const Context* c, int planes[3])
 {
     if (c->chain_slots < 0) return 0;
-    if (c->history_free || c->isolated || c->gate.on || c->cfg.mode == SN_MODE_FUSED) return 0;
+    if (c->history_free || c->isolated || c->cfg.mode == SN_MODE_FUSED) return 0;
     if (sn::pool_chain_lanes(c->cfg.bytes_per_sample, c->stride_e) < 2 || c->bh < 2) return 0;
     if (const char* e = getenv("SN_CHAIN"))
         if (atoi(e) == 0) return 0;
@@ -1048,6 +1048,10 @@ static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3]
     }
     sn::PlaneArgs pa[3];
     for (int p = 0; p < c->nplanes(); ++p) {
+        if (c->gate.on && !c->gate.waited[p]) {  // sn_process_host's plane pipeline: the chain needs every plane's copy
+            c->gate.waited[p] = true;
+            SN_HIP(c, hipStreamWaitEvent(st, c->gate.arrived[p], 0));
+        }
         sn::PlaneArgs& a = pa[p];
         a = sn::PlaneArgs{};
         a.src = static_cast<const uint8_t*>(src[p]) + (int64_t)f0 * sfs[p];
@@ -1115,7 +1119,8 @@ static int run_batch(Context* c, hipStream_t st, int slot0, int nframes, const v
         int g = f + 1;
         if (c->history_free || pn)
             while (g < nframes && field_offset(c, parity ? parity[g] : 1) == off) ++g;
-        int rc = !c->history_free && g - f > 1 ? run_chain(c, st, g - f, src, sfs, sp, dst, dfs, dp, f, off, planes, pn)
+        // (a single frame with two or three processed planes is a chain too: its passes follow each other rows apart)
+        int rc = !c->history_free && (g - f) * pn > 1 ? run_chain(c, st, g - f, src, sfs, sp, dst, dfs, dp, f, off, planes, pn)
                                                : run_group(c, st, slot0, g - f, src, sfs, sp, dst, dfs, dp, f, off);
         if (rc == SN_CHAIN_UNAVAILABLE) {  // nothing was queued yet: this frame and the rest one at a time
             g = f + 1;

@@ -109,7 +109,8 @@ typedef struct sn_info {
     int64_t band_fallbacks;   /* ... of which the check sent to the pool path (up to the     *
                                * last synchronisation)                                       */
     int64_t chained_frames;   /* frames of a history-carrying clip whose passes ran as one   *
-                               * chain (several frames per launch) instead of one at a time  */
+                               * chain (several frames per launch, or one frame with two or  *
+                               * three processed planes) instead of one pass at a time       */
 } sn_info;
 
 /* Create_SangNom2's argument checks, same order, same message text (src/SangNom2.cpp:407-422).
