@@ -1000,7 +1000,8 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
     return SN_OK;
 }
 
-// History-carrying clips, several frames of one field offset: the reference's passes -- every processed plane of every
+// History-carrying clips, two passes or more of one field offset (several frames, or one frame with two or three processed
+// planes): the reference's passes -- every processed plane of every
 // frame, in order, each starting from the pool the pass before it left -- as ONE chain (sn_pool_kernels.hip,
 // k_smooth_u8_chain): stage 1 of all passes into a slot each, one stage-2 launch that keeps several passes in
 // flight, stage 3 of all passes.  The pool of slot 0 is where the chain starts and where its last pass's pool ends
