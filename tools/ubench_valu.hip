@@ -1,18 +1,25 @@
-// ubench_valu.hip -- VALU issue microbenchmark for gfx950 (round 2 rewrite).
+// ubench_valu.hip -- VALU issue microbenchmark for gfx950 (round 3: wall-clock and residency checked).
 //
-// Round 1's version put every measured instruction into its own `asm volatile`, and hipcc pads an `s_nop 0`
-// after each of those: the 1- and 2-wave columns then measured instruction + nop pairs.  Here the whole unrolled
-// body (128 instructions) is ONE asm block with hard-coded registers, so nothing can be inserted between the
-// measured instructions (check: `hipcc -S --cuda-device-only` shows no s_nop inside the loops), and the time
-// comes from s_memtime inside the kernel (shader cycles, independent of the clock the chip holds).
+// The whole unrolled body (128 instructions) is ONE asm block with hard-coded registers, so nothing can be
+// inserted between the measured instructions (`hipcc -S --cuda-device-only` shows no s_nop inside the loops).
+//
+// Round 2 derived "cycles per wave-instruction and SIMD" from s_memtime inside each wave and ASSUMED that a launch
+// of `cus` workgroups of 256 x W threads puts W waves on every SIMD.  Its >= 3-wave columns came out above the
+// chip's vector peak, so this version trusts neither assumption:
+//   * occupancy is FORCED through the dynamic LDS size (workgroups of 256 threads = one wave per SIMD; 160 KB / W
+//     of LDS each, so exactly W workgroups fit a CU) and CHECKED with hipOccupancyMaxActiveBlocksPerMultiprocessor;
+//   * the grid is `rounds` x (cus x W) workgroups, so placement evens out and the figure is a THROUGHPUT:
+//     wave-instructions / (hipEvent wall time x SIMDs), printed in ns and in cycles of the clock the chip held,
+//     which is itself measured (s_memtime ticks per s_memrealtime tick, 100 MHz, inside the loaded waves);
+//   * the per-wave s_memtime figure of round 2 is printed next to it;
+//   * run under `rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` the same
+//     launches give a third, independent count (tools/ubench_pmc.py).
 //
 // For each instruction form:
 //   ind   eight independent accumulator chains (a result is consumed eight instructions later)
 //   dep   ONE dependent chain (every instruction consumes the previous result)
-// at 1, 2, 3, 4 and 8 waves per SIMD.  Output: cycles per wave-instruction as the SIMD sees it
-// (= wave cycles / instructions / waves per SIMD).
 // Also: mixes of fast and slow forms shaped like the fused sweep's row body.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o /tmp/ubench_valu && /tmp/ubench_valu
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o /tmp/ubench_valu && /tmp/ubench_valu [--waves 1,2,4,8] [name ...]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -32,20 +39,25 @@
 #define CLOB "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "vcc", "scc", "s10", "s11"
 
 #define DEFK(NAME, BODY128)                                                                                  \
-    __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long* out, int iters)                     \
+    __global__ void __launch_bounds__(256) k_##NAME(unsigned long long* out, int iters)                     \
     {                                                                                                        \
         asm volatile("v_mov_b32 v10, %0\n\tv_add_u32 v11, 1, %0\n\tv_add_u32 v12, 2, %0\n\tv_add_u32 v13, 3, %0\n\t" \
                      "v_add_u32 v14, 4, %0\n\tv_add_u32 v15, 5, %0\n\tv_add_u32 v16, 6, %0\n\tv_add_u32 v17, 7, %0\n\t" \
                      "v_mul_u32_u24 v18, 3, %0\n\tv_mul_u32_u24 v19, 5, %0\n\ts_mov_b64 s[10:11], 0x5555"       \
                      :: "v"(threadIdx.x) : CLOB);                                                            \
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                      \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                          \
         for (int i = 0; i < iters; ++i) asm volatile(BODY128 ::: CLOB);                                      \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                          \
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                      \
         unsigned r;                                                                                          \
         asm volatile("v_xor_b32 %0, v10, v11\n\tv_xor_b32 %0, %0, v12\n\tv_xor_b32 %0, %0, v13\n\tv_xor_b32 %0, %0, v14\n\t" \
                      "v_xor_b32 %0, %0, v15\n\tv_xor_b32 %0, %0, v16\n\tv_xor_b32 %0, %0, v17" : "=v"(r) :: CLOB); \
         const int gid = blockIdx.x * blockDim.x + threadIdx.x;                                               \
-        out[gid] = ((t1 - t0) << 8) | (r & 0xff);                                                            \
+        if ((threadIdx.x & 63) == 0) {                                                                       \
+            out[2 * (gid >> 6)] = ((t1 - t0) << 8) | (r & 0xff);                                             \
+            out[2 * (gid >> 6) + 1] = r1 - r0;                                                               \
+        }                                                                                                    \
     }
 
 #define STR2(x) #x
@@ -205,40 +217,72 @@ int main(int argc, char** argv)
         E3(add_e64_sgpr) E3(add_sgpr)
         {"mix 6 fast 2 salu", k_mix_f6salu2_ind},
     };
-    // optional arguments: substrings of the names to run
+    // arguments: [--waves 1,2,4] [--iters N] [--rounds R] substrings of the names to run
+    std::vector<int> wlist = {1, 2, 3, 4, 8};
+    int iters = 4000, rounds = 4;
+    std::vector<const char*> names;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--waves") && i + 1 < argc) {
+            wlist.clear();
+            for (char* t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) wlist.push_back(atoi(t));
+        } else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = atoi(argv[++i]);
+        else names.push_back(argv[i]);
+    }
     hipDeviceProp_t prop;
-    (void)hipGetDeviceProperties(&prop, 0);
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
-    unsigned long long* out;
-    const size_t n_out = (size_t)cus * 2 * 1024;
-    (void)hipMalloc(&out, n_out * sizeof(unsigned long long));
-    std::vector<unsigned long long> host(n_out);
-    const int iters = 2000;
     const int per_iter = 128;
-    printf("# %s, %d CUs; cycles per wave-instruction per SIMD (s_memtime inside the kernel), %d-instruction asm body x %d\n",
-           prop.name, cus, per_iter, iters);
-    printf("%-28s %7s %7s %7s %7s %7s\n", "instruction", "1w", "2w", "3w", "4w", "8w");
+    const size_t lds_cu = 160 * 1024;
+    unsigned long long* out;
+    const size_t max_waves = (size_t)cus * 8 * 4 * rounds;
+    if (hipMalloc(&out, max_waves * 2 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    std::vector<unsigned long long> host(max_waves * 2);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    printf("# %s, %d CUs (%d SIMDs); %d-instruction asm body x %d iterations; grid = %d rounds x CUs x W workgroups of 256 threads\n",
+           prop.name, cus, cus * 4, per_iter, iters, rounds);
+    printf("# per cell: ns per wave-instruction and SIMD by hipEvent wall time | cycles = ns x measured clock | the wave's own\n"
+           "# s_memtime cycles / instructions / W (round 2's figure) ; clock = s_memtime ticks per 10 ns of s_memrealtime, median wave\n");
+    printf("%-26s", "instruction");
+    for (int w : wlist) printf(" | W=%d: ns   cyc  wave-cyc/W  MHz occ", w);
+    printf("\n");
     for (auto& e : es) {
-        bool want = argc <= 1;
-        for (int i = 1; i < argc; ++i) want = want || strstr(e.name, argv[i]);
+        bool want = names.empty();
+        for (auto n : names) want = want || strstr(e.name, n);
         if (!want) continue;
-        const auto t_entry = std::chrono::steady_clock::now();
-        printf("%-28s", e.name);
-        for (int wps : {1, 2, 3, 4, 8}) {
-            // waves per CU = wps * 4 SIMDs; one block per CU up to 1024 threads, two blocks per CU for 8
-            const int blocks = wps == 8 ? 2 * cus : cus;
-            const int threads = wps == 8 ? 1024 : wps * 256;
-            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, iters);
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(host.data(), out, (size_t)blocks * threads * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            // median over waves of the wave's own cycle count
-            std::vector<unsigned long long> cyc;
-            for (size_t i = 0; i < (size_t)blocks * threads; i += 64) cyc.push_back(host[i] >> 8);
+        printf("%-26s", e.name);
+        for (int wps : wlist) {
+            // one workgroup = 4 waves = one per SIMD; W workgroups per CU through the LDS each one asks for
+            size_t lds = (lds_cu / wps) & ~(size_t)1023;
+            if (wps == 1) lds = 96 * 1024;
+            (void)hipFuncSetAttribute((const void*)e.k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            int occ = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, e.k, 256, lds);
+            const int blocks = cus * wps * rounds;
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), lds, 0, out, 16);   // warm the code path
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), lds, 0, out, iters);
+            (void)hipEventRecord(e1, 0);
+            if (hipEventSynchronize(e1) != hipSuccess) return 2;
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            const size_t waves = (size_t)blocks * 4;
+            (void)hipMemcpy(host.data(), out, waves * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            std::vector<double> cyc, mhz;
+            for (size_t i = 0; i < waves; ++i) {
+                const double c = (double)(host[2 * i] >> 8), r = (double)host[2 * i + 1];
+                cyc.push_back(c);
+                if (r > 0) mhz.push_back(c / r * 100.0);
+            }
             std::nth_element(cyc.begin(), cyc.begin() + cyc.size() / 2, cyc.end());
-            const double wave_cycles = (double)cyc[cyc.size() / 2];
-            printf(" %7.2f", wave_cycles / ((double)iters * per_iter) / wps);
+            std::nth_element(mhz.begin(), mhz.begin() + mhz.size() / 2, mhz.end());
+            const double wave_cycles = cyc[cyc.size() / 2], clk = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+            const double insts = (double)waves * iters * per_iter;
+            const double ns = (double)ms * 1e6 * (cus * 4.0) / insts;
+            printf(" | %9.3f %5.2f %9.2f %5.0f %2d", ns, ns * clk * 1e-3, wave_cycles / ((double)iters * per_iter) / wps, clk, occ);
         }
-        if (getenv("UB_WALL")) printf("  [%.2f s]", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count());
         printf("\n");
         fflush(stdout);
     }
