@@ -55,7 +55,7 @@ struct Line {
     unsigned P[PXL + 6];
     unsigned FB[PXL];  // F | B << 8 in each 16-bit half (both are 8-bit values)
     __device__ __forceinline__ unsigned F(int j) const { return FB[j] & kByte; }
-    __device__ __forceinline__ unsigned B(int j) const { return (FB[j] >> 8) & kByte; }
+    __device__ __forceinline__ unsigned B(int j) const { return pk_lshr8(FB[j]); }  // F < 256: one packed shift, no mask
 };
 
 struct RawHalf {  // left dword, own 8 bytes, right dword of one strip
@@ -91,9 +91,11 @@ __device__ __forceinline__ unsigned pair_byte(uint32_t hi_word, uint32_t lo_word
     return __builtin_amdgcn_perm(hi_word, lo_word, 0x0c040c00u + (unsigned)k * 0x00010001u);
 }
 
-__device__ __forceinline__ void unpack(Line& L, Raw q, const LaneRole& role)
+// loadPixel's clamp (SangNom2.cpp:25-34) for the two image-edge lanes: afterwards l / m0 m1 / r are the four pixels
+// left of the lane's eight, the eight, and the four right of them in every lane
+__device__ __forceinline__ Raw clamp_edges(Raw q, const LaneRole& role)
 {
-    if (role.edge_wave) {  // loadPixel's clamp (SangNom2.cpp:25-34) for the two image-edge lanes
+    if (role.edge_wave) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (role.first_mask & (h ? kHi : kLo)) {  // loaded from column 0: dwords are one slot early
@@ -105,6 +107,12 @@ __device__ __forceinline__ void unpack(Line& L, Raw q, const LaneRole& role)
             if (role.line_last_mask & (h ? kHi : kLo)) q.h[h].r = (q.h[h].m1 >> 24) * 0x01010101u;
         }
     }
+    return q;
+}
+
+// q: after clamp_edges()
+__device__ __forceinline__ void unpack(Line& L, const Raw& q)
+{
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         L.P[k] = pair_byte(q.h[1].l, q.h[0].l, k + 1);
@@ -133,20 +141,28 @@ __device__ __forceinline__ void unpack(Line& L, Raw q, const LaneRole& role)
     }
 }
 
-// Stage 1, buffer BUF, packed position j, pair (c, n); Buffers enum of SangNom2.h:8-20.
+// Stage 1, buffer BUF, packed position j, pair (c, n): the two values whose difference is the cost; Buffers enum of
+// SangNom2.h:8-20.
+template <int BUF>
+__device__ __forceinline__ void cost_operands(const Line& c, const Line& n, int j, unsigned& x, unsigned& y)
+{
+    const int i = j + 3;
+    if constexpr (BUF == 0) { x = c.P[i - 3]; y = n.P[i + 3]; }
+    else if constexpr (BUF == 1) { x = c.P[i - 2]; y = n.P[i + 2]; }
+    else if constexpr (BUF == 2) { x = c.P[i - 1]; y = n.P[i + 1]; }
+    else if constexpr (BUF == 3) { x = c.F(j); y = n.B(j); }  // |forwardSangNom1 - forwardSangNom2|
+    else if constexpr (BUF == 4) { x = c.P[i]; y = n.P[i]; }
+    else if constexpr (BUF == 5) { x = c.B(j); y = n.F(j); }  // |backwardSangNom1 - backwardSangNom2|
+    else if constexpr (BUF == 6) { x = c.P[i + 1]; y = n.P[i - 1]; }
+    else if constexpr (BUF == 7) { x = c.P[i + 2]; y = n.P[i - 2]; }
+    else { x = c.P[i + 3]; y = n.P[i - 3]; }
+}
 template <int BUF>
 __device__ __forceinline__ unsigned cost(const Line& c, const Line& n, int j)
 {
-    const int i = j + 3;
-    if constexpr (BUF == 0) return pk_absdiff(c.P[i - 3], n.P[i + 3]);
-    if constexpr (BUF == 1) return pk_absdiff(c.P[i - 2], n.P[i + 2]);
-    if constexpr (BUF == 2) return pk_absdiff(c.P[i - 1], n.P[i + 1]);
-    if constexpr (BUF == 3) return pk_absdiff(c.F(j), n.B(j));  // |forwardSangNom1 - forwardSangNom2|
-    if constexpr (BUF == 4) return pk_absdiff(c.P[i], n.P[i]);
-    if constexpr (BUF == 5) return pk_absdiff(c.B(j), n.F(j));  // |backwardSangNom1 - backwardSangNom2|
-    if constexpr (BUF == 6) return pk_absdiff(c.P[i + 1], n.P[i - 1]);
-    if constexpr (BUF == 7) return pk_absdiff(c.P[i + 2], n.P[i - 2]);
-    return pk_absdiff(c.P[i + 3], n.P[i - 3]);
+    unsigned x, y;
+    cost_operands<BUF>(c, n, j, x, y);
+    return pk_absdiff(x, y);
 }
 
 // Stage 3: a + b of the candidate that belongs to buffer BUF (SangNom2.cpp:214-249).
@@ -165,12 +181,80 @@ __device__ __forceinline__ unsigned tap_sum(const Line& c, const Line& n, int j)
     return c.P[i + 3] + n.P[i - 3];
 }
 
+// ---- Stage 3 in the byte domain (planes on their own) ---------------------------------------------------------------
+// The ladder's winner picks, per pixel, ONE byte of the upper line and ONE byte of the lower line (SangNom2.cpp:214-249:
+// c(k) and n(-k) for k = -3 .. 3, or the two SangNom values), and the result is their rounded average.  In the packed
+// pair layout that is nine tap sums and an eight-select tree per register (31 instructions per pixel pair).  On the
+// lines as they lie in memory -- four pixels per dword -- it is a handful of byte permutes whose SELECTORS are data:
+//   * the rank code of the winner (low nibble of the minimum key) indexes a byte table through v_perm_b32
+//     (selector 0..7 -> table byte, 12 -> 0x00): sel_c = 3 + k;  the lower line's selector is 6 - sel_c;
+//   * two neighbouring pixels x, x+1 find all their candidates c(x-3) .. c(x+4) in ONE 8-byte window, so a v_perm_b32
+//     over that window with selectors (3 + k0, 4 + k1) fetches both; the windows of a lane's eight pixels are six
+//     dwords per strip, cut with v_alignbyte_b32 once per line and kept in LDS for the two rows that use the line;
+//   * the SangNom candidates are two more byte permutes (take the F / B byte where the code says so);
+//   * v_lerp_u8 with 0x01010101 is (a + b + 1) >> 1 on four pixels at once.
+// 18 instructions per four pixels of a strip instead of 124, and the result is already in memory order.
+struct RawLine {
+    unsigned W[2][6];  // per strip: [p-3..p0] [p1..p4] [p-1..p2] [p3..p6] [p5..p8] [p7..p10] (p0 = the lane's first pixel)
+    unsigned F[2][2], B[2][2];  // forward / backward SangNom values of p0..p3 and p4..p7, one byte each
+};
+// rank codes: P4 (and the `minBuf > aaf` arm, same result) 0, P5 1, P3 2, P6 3, P2 4, P7 5, P1 6, P8 7, P0 12
+constexpr unsigned kLutLo = 0x04030303u, kLutHi = 0x06010502u;  // code -> 3 + k; code 12 reads 0x00 = 3 + (-3)
+
+__device__ __forceinline__ void make_raw(RawLine& R, const Raw& q, const Line& L)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const RawHalf& x = q.h[h];
+        R.W[h][0] = __builtin_amdgcn_alignbyte(x.m0, x.l, 1);
+        R.W[h][1] = __builtin_amdgcn_alignbyte(x.m1, x.m0, 1);
+        R.W[h][2] = __builtin_amdgcn_alignbyte(x.m0, x.l, 3);
+        R.W[h][3] = __builtin_amdgcn_alignbyte(x.m1, x.m0, 3);
+        R.W[h][4] = __builtin_amdgcn_alignbyte(x.r, x.m1, 1);
+        R.W[h][5] = __builtin_amdgcn_alignbyte(x.r, x.m1, 3);
+    }
+    // FB[j] = [F lo strip, B lo strip, F hi strip, B hi strip]: a 4 x 4 byte transpose per four registers
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const unsigned u01 = __builtin_amdgcn_perm(L.FB[4 * g + 1], L.FB[4 * g + 0], 0x05010400u);  // [F0 F1 B0 B1] lo strip
+        const unsigned u23 = __builtin_amdgcn_perm(L.FB[4 * g + 3], L.FB[4 * g + 2], 0x05010400u);
+        const unsigned v01 = __builtin_amdgcn_perm(L.FB[4 * g + 1], L.FB[4 * g + 0], 0x07030602u);  // ... hi strip
+        const unsigned v23 = __builtin_amdgcn_perm(L.FB[4 * g + 3], L.FB[4 * g + 2], 0x07030602u);
+        R.F[0][g] = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+        R.B[0][g] = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+        R.F[1][g] = __builtin_amdgcn_perm(v23, v01, 0x05040100u);
+        R.B[1][g] = __builtin_amdgcn_perm(v23, v01, 0x07060302u);
+    }
+}
+
+// four interpolated pixels of strip h, group g (pixels 4g .. 4g+3), from the rank codes of their winners
+__device__ __forceinline__ unsigned interpolate4(const RawLine& c, const RawLine& n, int h, int g, unsigned codes)
+{
+    const unsigned sc = __builtin_amdgcn_perm(kLutHi, kLutLo, codes) + 0x01000100u;  // [3 + k0, 4 + k1, 3 + k2, 4 + k3]
+    const unsigned sn = 0x08060806u - sc;                                          // [3 - k0, 4 - k1, 3 - k2, 4 - k3]
+    const int a = g == 0 ? 0 : 1, b = g == 0 ? 1 : 4;  // window of pixels 0, 1 of the group: dwords W[a], W[b]
+    const int d = g == 0 ? 2 : 3, e = g == 0 ? 3 : 5;  // ... of pixels 2, 3
+    unsigned cc = bfi(0x0000ffffu, __builtin_amdgcn_perm(c.W[h][b], c.W[h][a], sc), __builtin_amdgcn_perm(c.W[h][e], c.W[h][d], sc));
+    unsigned nn = bfi(0x0000ffffu, __builtin_amdgcn_perm(n.W[h][b], n.W[h][a], sn), __builtin_amdgcn_perm(n.W[h][e], n.W[h][d], sn));
+    // P5 (code 1): avg(backwardSangNom1, backwardSangNom2) = c.B, n.F;  P3 (code 2): avg(forward1, forward2) = c.F, n.B
+    const unsigned sb = __builtin_amdgcn_perm(0u, 0x00000400u, codes) + 0x03020100u;  // byte i: i, or 4 + i where the code is 1
+    const unsigned sf = __builtin_amdgcn_perm(0u, 0x00040000u, codes) + 0x03020100u;  // ... where the code is 2
+    cc = __builtin_amdgcn_perm(c.B[h][g], cc, sb);
+    nn = __builtin_amdgcn_perm(n.F[h][g], nn, sb);
+    cc = __builtin_amdgcn_perm(c.F[h][g], cc, sf);
+    nn = __builtin_amdgcn_perm(n.B[h][g], nn, sf);
+    return __builtin_amdgcn_lerp(cc, nn, 0x01010101u);  // (a + b + 1) >> 1 per byte, SangNom2.cpp:48-52
+}
+
 // rank of buffer BUF in the reference's ladder: P4, P5, P3, P6, P2, P7, P1, P8, P0 -> 1..9
-template <int BUF>
+// ... -> the codes of the byte-domain stage 3 (see RawLine) where that runs
+__host__ __device__ constexpr bool raw_stage3(int mode) { return !has_pools(mode); }
+template <int BUF, int MODE>
 constexpr unsigned rank_of()
 {
     constexpr unsigned r[9] = {9, 7, 5, 3, 1, 2, 4, 6, 8};
-    return r[BUF] * 0x00010001u;
+    constexpr unsigned code[9] = {12, 6, 4, 2, 0, 1, 3, 5, 7};
+    return (raw_stage3(MODE) ? code[BUF] : r[BUF]) * 0x00010001u;
 }
 
 template <bool EDGE>
@@ -255,6 +339,7 @@ struct RowCtx {  // what a row needs besides the lines
     int vout_hi;         // like vout (= the low half's chunk), for the high half's chunk
     bool any_out;        // wave-uniform: some lane of this wave stores in this row
     int vout;       // voffset for this row's O in pool_out (out of range: not kept)
+    int slot_c, slot_n;  // byte-domain stage 3: LDS slots of the lines above / below the interpolated one
 };
 
 // S1: the costs of row r+1 come from the lines (n, nn); otherwise they are zero (kPlain /
@@ -265,6 +350,29 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
                                             PoolIO::RawPair& stale)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
+    if constexpr (MODE == kPlain && S1) {
+        // A plane on its own never needs the cost itself: |x - y| = (x -sat y) + (y -sat x), so S = A + U + V and
+        // A' = O + U + V are one three-operand add each -- two saturating subtracts and two v_add3 where maximum,
+        // minimum, subtract and two adds took five instructions (every one costs the same issue slot here).
+        unsigned U[PXL], V[PXL];
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+            unsigned x, y;
+            cost_operands<BUF>(n, nn, j, x, y);
+            U[j] = pk_sub_sat(x, y);
+            V[j] = pk_sub_sat(y, x);
+            S[j] = add3(A[j], U[j], V[j]);
+        }
+        if (role.edge_wave) box7<true>(S, Bx, role);
+        else box7<false>(S, Bx, role);
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());
+            A[j] = add3(pk_lshr4(key), U[j], V[j]);
+            kmin[j] = pk_min(kmin[j], key);
+        }
+        return;
+    }
     if constexpr (chroma_mode(MODE)) {
         io.finish(stale, D);
         // the stale row of the buffer after next is fetched into the registers this one has just left (two buffer steps
@@ -295,13 +403,13 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             const unsigned t = Bx[j] & 0x0ff00ff0u;  // O << 4, shared by O and the key
             O[j] = t >> 4;                           // (sum / 16) wraps to uint8_t, SangNom2.cpp:152
             A[j] = O[j] + D[j];                      // O + D[r+1]
-            kmin[j] = pk_min(kmin[j], t | rank_of<BUF>());
+            kmin[j] = pk_min(kmin[j], t | rank_of<BUF, MODE>());
         } else {
             // key = (sum / 16 mod 256) << 4 | rank in ONE v_and_or_b32; the rank (< 16) falls off the PACKED shift that
             // yields O (a 32-bit shift would push the high half's rank into the low half).  With two waves per SIMD
             // every VALU instruction costs about the same (profiles/r2_ubench_valu_issue_rates.txt), so what counts is
             // the NUMBER of instructions: 4 here, 5 above.
-            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF>());
+            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());
             O[j] = pk_lshr4(key);
             A[j] = O[j] + D[j];
             kmin[j] = pk_min(kmin[j], key);
@@ -327,14 +435,18 @@ struct Out {
 // Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
 // The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
 // in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
-__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : 9; }
+#ifndef SN_PLAIN_RB
+#define SN_PLAIN_RB 9
+#endif
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : mode == kPlain ? SN_PLAIN_RB : 9; }
 template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
     static constexpr int kRegBuffers = RB;
-    uint4* v;    // [6][NT]: the parked line
+    uint4* v;    // [6][NT]: the parked line; byte-domain stage 3: [3 lines][5][NT], line k in slot k % 3 (RawLine)
     uint4* a;    // [kBuffers - RB][2][NT]: A of the LDS-resident buffers, thread-private slots
 };
+__host__ __device__ constexpr int parked_line_slots(int mode) { return raw_stage3(mode) ? 15 : 6; }
 
 template <int NT, int RB>
 __device__ __forceinline__ void load_A(const Parked<NT, RB>& pk, int tid, int b, unsigned (&A)[PXL])
@@ -359,6 +471,28 @@ __device__ __forceinline__ void park_line(const Parked<NT, RB>& pk, int tid, con
     pk.v[3 * pk.nthreads + tid] = make_uint4(L.P[12], L.P[13], L.FB[0], L.FB[1]);
     pk.v[4 * pk.nthreads + tid] = make_uint4(L.FB[2], L.FB[3], L.FB[4], L.FB[5]);
     pk.v[5 * pk.nthreads + tid] = make_uint4(L.FB[6], L.FB[7], 0u, 0u);
+}
+
+template <int NT, int RB>
+__device__ __forceinline__ void park_raw(const Parked<NT, RB>& pk, int tid, int slot, const RawLine& R)
+{
+    uint4* to = pk.v + slot * 5 * pk.nthreads + tid;
+    to[0 * pk.nthreads] = make_uint4(R.W[0][0], R.W[0][1], R.W[0][2], R.W[0][3]);
+    to[1 * pk.nthreads] = make_uint4(R.W[0][4], R.W[0][5], R.W[1][0], R.W[1][1]);
+    to[2 * pk.nthreads] = make_uint4(R.W[1][2], R.W[1][3], R.W[1][4], R.W[1][5]);
+    to[3 * pk.nthreads] = make_uint4(R.F[0][0], R.F[0][1], R.B[0][0], R.B[0][1]);
+    to[4 * pk.nthreads] = make_uint4(R.F[1][0], R.F[1][1], R.B[1][0], R.B[1][1]);
+}
+template <int NT, int RB>
+__device__ __forceinline__ void unpark_raw(const Parked<NT, RB>& pk, int tid, int slot, RawLine& R)
+{
+    const uint4* from = pk.v + slot * 5 * pk.nthreads + tid;
+    const uint4 a = from[0 * pk.nthreads], b = from[1 * pk.nthreads], c = from[2 * pk.nthreads], d = from[3 * pk.nthreads], e = from[4 * pk.nthreads];
+    R.W[0][0] = a.x; R.W[0][1] = a.y; R.W[0][2] = a.z; R.W[0][3] = a.w;
+    R.W[0][4] = b.x; R.W[0][5] = b.y; R.W[1][0] = b.z; R.W[1][1] = b.w;
+    R.W[1][2] = c.x; R.W[1][3] = c.y; R.W[1][4] = c.z; R.W[1][5] = c.w;
+    R.F[0][0] = d.x; R.F[0][1] = d.y; R.B[0][0] = d.z; R.B[0][1] = d.w;
+    R.F[1][0] = e.x; R.F[1][1] = e.y; R.B[1][0] = e.z; R.B[1][1] = e.w;
 }
 
 template <int NT, int RB>
@@ -422,6 +556,22 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 
     Out o{};
     if constexpr (!S3) return o;
+    if constexpr (raw_stage3(MODE)) {
+        // rank codes of the eight winners of each strip, four to a dword in pixel order (RawLine has the rest)
+        RawLine c, nr;
+        unpark_raw(pk, tid, rc.slot_c, c);
+        unpark_raw(pk, tid, rc.slot_n, nr);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const unsigned t01 = __builtin_amdgcn_perm(kmin[4 * g + 1], kmin[4 * g + 0], 0x06020400u);  // [lo0 lo1 hi0 hi1]
+            const unsigned t23 = __builtin_amdgcn_perm(kmin[4 * g + 3], kmin[4 * g + 2], 0x06020400u);
+            const unsigned lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) & 0x0f0f0f0fu;
+            const unsigned hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u) & 0x0f0f0f0fu;
+            o.lo[g] = interpolate4(c, nr, 0, g, lo);
+            o.hi[g] = interpolate4(c, nr, 1, g, hi);
+        }
+        return o;
+    }
     // winner's rank -> tap sum -> average
     Line c;
     unpark_line(pk, tid, c);
@@ -481,7 +631,7 @@ struct Mailbox {  // [copy][wave 0..NW-1][side][slot][72][2 halves] 16-bit entri
 
 __host__ __device__ constexpr int lds_bytes(int nw, int mode)
 {
-    return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + mailbox_copies(mode) * nw * 2 * GH * kBuffers * PXL * 4;
+    return (parked_line_slots(mode) + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + mailbox_copies(mode) * nw * 2 * GH * kBuffers * PXL * 4;
 }
 
 template <int NW, int MODE, bool BAND>
@@ -497,7 +647,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     constexpr int kRegBuffers = reg_buffers(MODE);
     Parked<NW * 64, kRegBuffers> parked;
     parked.v = reinterpret_cast<uint4*>(lds_raw + sub * lds_bytes(NW, MODE));
-    parked.a = parked.v + 6 * NW * 64;
+    parked.a = parked.v + parked_line_slots(MODE) * NW * 64;
     Mailbox<NW, mailbox_copies(MODE)> mb;
     mb.h = reinterpret_cast<unsigned short*>(parked.a + (kBuffers - kRegBuffers) * 2 * NW * 64);
     const int wave = tid >> 6;
@@ -654,9 +804,20 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     keep(dst_line, q0, top);
     if (a.offset == 1) keep(0, q0, top);  // the line that cannot be interpolated, SangNom2.cpp:386-391
     if (nk > 1) keep(dst_line + r0 * dst_step, q1, r0 == ra && r0 <= nr);
-    unpack(L0, q0, role);
-    unpack(L1, q1, role);
-    park_line(parked, tid, L0);  // c of row 1
+    {
+        const Raw f0 = clamp_edges(q0, role), f1 = clamp_edges(q1, role);
+        unpack(L0, f0);
+        unpack(L1, f1);
+        if constexpr (raw_stage3(MODE)) {
+            RawLine R;
+            make_raw(R, f0, L0);
+            park_raw(parked, tid, (r0 - 1) % 3, R);  // K[r0 - 1]: c of row r0
+            make_raw(R, f1, L1);
+            park_raw(parked, tid, r0 % 3, R);        // K[r0]: n of row r0
+        } else {
+            park_line(parked, tid, L0);  // c of row 1
+        }
+    }
 
     // A[1] = O[0] + P[1] = P[1] (pool row 0 is never written: zero); P[1] = stage-1 costs of the first
     // line pair, and outside the chroma region (kChroma) what the previous pass left in row 1
@@ -725,7 +886,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         turns.update();
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
-            unpack(nn, qn, role);  // waits for the line prefetched one row ago
+            const Raw fq = clamp_edges(qn, role);  // waits for the line prefetched one row ago
+            unpack(nn, fq);
+            if constexpr (raw_stage3(MODE)) {
+                RawLine R;
+                make_raw(R, fq, nn);
+                park_raw(parked, tid, (r + 1) % 3, R);  // K[r + 1]: n of the next row, c of the one after
+            }
             keep(dst_keep, qn, !BAND || (r + 1 >= ra && r < rb));
             dst_keep += dst_step;
         }
@@ -757,6 +924,8 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         rc.r = r;
         rc.vin_lo = rc.vin_hi = rc.vout = rc.vout_hi = kOutOfRange;
         rc.any_out = false;
+        rc.slot_c = (r - 1) % 3;
+        rc.slot_n = r % 3;
         if constexpr (chroma_mode(MODE)) {
             const bool row_in = r + 1 <= a.rows_in;
             rc.vin_lo = (row_in && in_cone(r + 1, a.cone_in, 0)) ? io.v_lo : kOutOfRange;
@@ -771,7 +940,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         const Out o = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S3) put(out_row, o);  // stored at once: nothing is carried into the next row
         out_row += dst_step;
-        if constexpr (HAS_NEXT) park_line(parked, tid, n);  // n is the next row's c
+        if constexpr (HAS_NEXT && !raw_stage3(MODE)) park_line(parked, tid, n);  // n is the next row's c
         if (r < sweep) {
             if (r % K == 0) {
                 if constexpr (mailbox_copies(MODE) == 1) __syncthreads();  // the previous refresh has been taken out

@@ -145,6 +145,26 @@ __device__ __forceinline__ unsigned pk_lshr4(unsigned v)
     const u16x2 four = {4, 4};
     return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, v) >> four));  // v_pk_lshrrev_b16
 }
+// both halves shifted right by 8
+__device__ __forceinline__ unsigned pk_lshr8(unsigned v)
+{
+    const u16x2 eight = {8, 8};
+    return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, v) >> eight));  // v_pk_lshrrev_b16
+}
+// max(a - b, 0) in both halves: v_pk_sub_u16 with clamp
+__device__ __forceinline__ unsigned pk_sub_sat(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + b + c as ONE instruction (left to itself the compiler forms b + c first where two such sums share it)
+__device__ __forceinline__ unsigned add3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // (a & m) | c with a wave-uniform c (the one scalar operand the encoding allows)
 __device__ __forceinline__ unsigned and_or(unsigned a, unsigned m, unsigned c)
 {
