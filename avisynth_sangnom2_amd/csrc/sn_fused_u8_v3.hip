@@ -57,6 +57,15 @@ struct Line {
     __device__ __forceinline__ unsigned F(int j) const { return FB[j] & kByte; }
     __device__ __forceinline__ unsigned B(int j) const { return pk_lshr8(FB[j]); }  // F < 256: one packed shift, no mask
 };
+// The same with F and B in registers of their own: eight registers more per line, no extraction per use.  For the
+// sweeps whose stage 3 runs in the byte domain: there a line in this form only serves stage 1, two of them are live,
+// and the kernel has the registers.
+struct WideLine {
+    unsigned P[PXL + 6];
+    unsigned Fv[PXL], Bv[PXL];
+    __device__ __forceinline__ unsigned F(int j) const { return Fv[j]; }
+    __device__ __forceinline__ unsigned B(int j) const { return Bv[j]; }
+};
 
 struct RawHalf {  // left dword, own 8 bytes, right dword of one strip
     uint32_t l, m0, m1, r;
@@ -111,7 +120,8 @@ __device__ __forceinline__ Raw clamp_edges(Raw q, const LaneRole& role)
 }
 
 // q: after clamp_edges()
-__device__ __forceinline__ void unpack(Line& L, const Raw& q)
+template <class LineT>
+__device__ __forceinline__ void unpack(LineT& L, const Raw& q)
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -136,15 +146,20 @@ __device__ __forceinline__ void unpack(Line& L, const Raw& q)
     for (int j = 0; j < PXL; ++j) {
         const unsigned q5 = Q4[j + 1] + L.P[j + 3];
         const unsigned f = ((Q4[j] + q5 + M[j + 2]) >> 3) & kByte;
-        const unsigned b = ((Q4[j + 2] + q5 + M[j]) << 5) & 0xff00ff00u;  // (x >> 3 & 255) << 8
-        L.FB[j] = f | b;
+        if constexpr (std::is_same<LineT, WideLine>::value) {
+            L.Fv[j] = f;
+            L.Bv[j] = ((Q4[j + 2] + q5 + M[j]) >> 3) & kByte;
+        } else {
+            const unsigned b = ((Q4[j + 2] + q5 + M[j]) << 5) & 0xff00ff00u;  // (x >> 3 & 255) << 8
+            L.FB[j] = f | b;
+        }
     }
 }
 
 // Stage 1, buffer BUF, packed position j, pair (c, n): the two values whose difference is the cost; Buffers enum of
 // SangNom2.h:8-20.
-template <int BUF>
-__device__ __forceinline__ void cost_operands(const Line& c, const Line& n, int j, unsigned& x, unsigned& y)
+template <int BUF, class LineT>
+__device__ __forceinline__ void cost_operands(const LineT& c, const LineT& n, int j, unsigned& x, unsigned& y)
 {
     const int i = j + 3;
     if constexpr (BUF == 0) { x = c.P[i - 3]; y = n.P[i + 3]; }
@@ -157,8 +172,8 @@ __device__ __forceinline__ void cost_operands(const Line& c, const Line& n, int 
     else if constexpr (BUF == 7) { x = c.P[i + 2]; y = n.P[i - 2]; }
     else { x = c.P[i + 3]; y = n.P[i - 3]; }
 }
-template <int BUF>
-__device__ __forceinline__ unsigned cost(const Line& c, const Line& n, int j)
+template <int BUF, class LineT>
+__device__ __forceinline__ unsigned cost(const LineT& c, const LineT& n, int j)
 {
     unsigned x, y;
     cost_operands<BUF>(c, n, j, x, y);
@@ -201,7 +216,7 @@ struct RawLine {
 // rank codes: P4 (and the `minBuf > aaf` arm, same result) 0, P5 1, P3 2, P6 3, P2 4, P7 5, P1 6, P8 7, P0 12
 constexpr unsigned kLutLo = 0x04030303u, kLutHi = 0x06010502u;  // code -> 3 + k; code 12 reads 0x00 = 3 + (-3)
 
-__device__ __forceinline__ void make_raw(RawLine& R, const Raw& q, const Line& L)
+__device__ __forceinline__ void make_raw(RawLine& R, const Raw& q, const WideLine& L)
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -213,17 +228,15 @@ __device__ __forceinline__ void make_raw(RawLine& R, const Raw& q, const Line& L
         R.W[h][4] = __builtin_amdgcn_alignbyte(x.r, x.m1, 1);
         R.W[h][5] = __builtin_amdgcn_alignbyte(x.r, x.m1, 3);
     }
-    // FB[j] = [F lo strip, B lo strip, F hi strip, B hi strip]: a 4 x 4 byte transpose per four registers
+    // F[j] = [lo strip, 0, hi strip, 0]: pixels j, j+1 side by side, then the four of a strip into one dword
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const unsigned u01 = __builtin_amdgcn_perm(L.FB[4 * g + 1], L.FB[4 * g + 0], 0x05010400u);  // [F0 F1 B0 B1] lo strip
-        const unsigned u23 = __builtin_amdgcn_perm(L.FB[4 * g + 3], L.FB[4 * g + 2], 0x05010400u);
-        const unsigned v01 = __builtin_amdgcn_perm(L.FB[4 * g + 1], L.FB[4 * g + 0], 0x07030602u);  // ... hi strip
-        const unsigned v23 = __builtin_amdgcn_perm(L.FB[4 * g + 3], L.FB[4 * g + 2], 0x07030602u);
-        R.F[0][g] = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
-        R.B[0][g] = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
-        R.F[1][g] = __builtin_amdgcn_perm(v23, v01, 0x05040100u);
-        R.B[1][g] = __builtin_amdgcn_perm(v23, v01, 0x07060302u);
+        const unsigned f01 = L.Fv[4 * g + 0] | (L.Fv[4 * g + 1] << 8), f23 = L.Fv[4 * g + 2] | (L.Fv[4 * g + 3] << 8);  // [lo0 lo1 hi0 hi1]
+        const unsigned b01 = L.Bv[4 * g + 0] | (L.Bv[4 * g + 1] << 8), b23 = L.Bv[4 * g + 2] | (L.Bv[4 * g + 3] << 8);
+        R.F[0][g] = __builtin_amdgcn_perm(f23, f01, 0x05040100u);
+        R.F[1][g] = __builtin_amdgcn_perm(f23, f01, 0x07060302u);
+        R.B[0][g] = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
+        R.B[1][g] = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
     }
 }
 
@@ -342,10 +355,13 @@ struct RowCtx {  // what a row needs besides the lines
     int slot_c, slot_n;  // byte-domain stage 3: LDS slots of the lines above / below the interpolated one
 };
 
+template <int MODE>
+using LineOf = typename std::conditional<raw_stage3(MODE), WideLine, Line>::type;
+
 // S1: the costs of row r+1 come from the lines (n, nn); otherwise they are zero (kPlain /
 // kLumaSpill: row bh is never written) or the previous pass's values (kChroma).
 template <int BUF, int MODE, bool S1>
-__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
+__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const LineOf<MODE>& n, const LineOf<MODE>& nn,
                                             const LaneRole& role, const PoolIO& io, const RowCtx& rc,
                                             PoolIO::RawPair& stale)
 {
@@ -474,6 +490,8 @@ __device__ __forceinline__ void park_line(const Parked<NT, RB>& pk, int tid, con
 }
 
 template <int NT, int RB>
+__device__ __forceinline__ void park_line(const Parked<NT, RB>&, int, const WideLine&) {}  // never called: stage 3 in the byte domain parks a RawLine
+template <int NT, int RB>
 __device__ __forceinline__ void park_raw(const Parked<NT, RB>& pk, int tid, int slot, const RawLine& R)
 {
     uint4* to = pk.v + slot * 5 * pk.nthreads + tid;
@@ -509,8 +527,8 @@ __device__ __forceinline__ void unpark_line(const Parked<NT, RB>& pk, int tid, L
 
 // S3: the row has an interpolated line (stage 3); kChroma sweeps one extra row without one.
 template <int MODE, bool S1, bool S3, int NT>
-__device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk, int tid, const Line& n,
-                                        const Line& nn, const LaneRole& role, unsigned thr_key, const PoolIO& io,
+__device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk, int tid, const LineOf<MODE>& n,
+                                        const LineOf<MODE>& nn, const LaneRole& role, unsigned thr_key, const PoolIO& io,
                                         const RowCtx& rc)
 {
     unsigned kmin[PXL];
@@ -572,6 +590,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
         }
         return o;
     }
+    else {
     // winner's rank -> tap sum -> average
     Line c;
     unpark_line(pk, tid, c);
@@ -607,6 +626,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
         o.hi[g] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);  // [t01.b2, t01.b3, t23.b2, t23.b3]
     }
     return o;
+    }
 }
 
 // LDS mailbox, receiver-ready: word [refresh parity][wave W][side][slot][i] is what ghost lane
@@ -798,7 +818,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     const unsigned thr_key = (unsigned)((a.thr + 1) << 4) * 0x00010001u;
 
     // a band copies the kept lines ra .. rb (the top band line 0 as well)
-    Line L0, L1;
+    LineOf<MODE> L0, L1;
     Raw q0 = load_raw(src_line + (r0 - 1) * src_step);
     Raw q1 = nk > 1 ? load_raw(src_line + r0 * src_step) : q0;
     keep(dst_line, q0, top);
@@ -880,7 +900,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // interpolated line).
     TurnTaking turns;
     turns.init(a.turn_shift);
-    auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
+    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag) {
         constexpr bool HAS_NEXT = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
         turns.update();
@@ -1028,7 +1048,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         if (rb == nr) step(nr, L1, L0, F{}, T{});
         if (rb < last) leave_state(1);
     } else {
-        for (int r = 1; r < nr; ++r) {
+        // two rows per trip with the roles of the two line registers swapped, so that no row ends in a copy of a line
+        int r = 1;
+        for (; r + 1 < nr; r += 2) {
+            step(r, L1, L0, T{}, T{});
+            step(r + 1, L0, L1, T{}, T{});
+        }
+        if (r < nr) {
             step(r, L1, L0, T{}, T{});
             L1 = L0;
         }
