@@ -270,25 +270,36 @@ constexpr unsigned rank_of()
     return (raw_stage3(MODE) ? code[BUF] : r[BUF]) * 0x00010001u;
 }
 
-template <bool EDGE>
+// The 7-tap box over S with the line buffer's clamps (SangNom2.cpp:144-150), the same instructions in every wave:
+//   * column 0 is lane 0 of the first strip, and lane 0 has no left neighbour: its DPP move keeps the `old` operand,
+//     S[0] -- the clamp.  (Lane 0 of every other strip is the outermost ghost lane, whose value is wrong by design.)
+//   * the last column sits in some lane of the last strip: a select per right-hand tap there (RCLAMP; every wave runs it
+//     unless SN_RCLAMP_BRANCH asks for a wave-uniform branch around it).
+// Round 2 branched on "this wave holds an image edge" around two whole variants of the box: the edge waves paid 29
+// instructions per buffer instead of 20, the branch cut every buffer step into three scheduling regions, and the seam
+// refresh made every wave wait for the slowest (knocking the edge variant out -- wrong at the edges -- ran 12 % faster).
+template <bool RCLAMP>
 __device__ __forceinline__ void box7(const unsigned (&S)[PXL], unsigned (&Bx)[PXL], const LaneRole& role)
 {
     unsigned L[3], R[3];
-    if constexpr (EDGE) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            L[k] = bfi(role.first_mask, S[0], dpp_from_left(S[PXL - 3 + k]));        // clamp to column 0
-            R[k] = bfi(role.last_mask, S[PXL - 1], dpp_from_right(S[k]));            // clamp to column w-1
-        }
+    for (int k = 0; k < 3; ++k) {
+        L[k] = dpp_from_left_or(S[0], S[PXL - 3 + k]);
+        R[k] = dpp_from_right(S[k]);
+        if constexpr (RCLAMP) R[k] = bfi(role.last_mask, S[PXL - 1], R[k]);  // clamp to column w-1
     }
-    auto X = [&](int i) -> unsigned {
-        if (i < 0) return EDGE ? L[i + 3] : dpp_from_left(S[PXL + i]);
-        if (i >= PXL) return EDGE ? R[i - PXL] : dpp_from_right(S[i - PXL]);
-        return S[i];
-    };
+    auto X = [&](int i) -> unsigned { return i < 0 ? L[i + 3] : i >= PXL ? R[i - PXL] : S[i]; };
     Bx[0] = S[0] + S[1] + S[2] + S[3] + X(-1) + X(-2) + X(-3);
 #pragma unroll
     for (int j = 0; j + 1 < PXL; ++j) Bx[j + 1] = Bx[j] - X(j - 3) + X(j + 4);
+}
+#ifndef SN_RCLAMP_BRANCH
+#define SN_RCLAMP_BRANCH 0
+#endif
+__device__ __forceinline__ void box7_any(const unsigned (&S)[PXL], unsigned (&Bx)[PXL], const LaneRole& role)
+{
+    if (SN_RCLAMP_BRANCH && !role.edge_wave) box7<false>(S, Bx, role);
+    else box7<true>(S, Bx, role);
 }
 
 // Access to the scratch pools of the chroma coupling (see Mode).  A thread has two 8-byte chunks in a pool row:
@@ -379,8 +390,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             V[j] = pk_sub_sat(y, x);
             S[j] = add3(A[j], U[j], V[j]);
         }
-        if (role.edge_wave) box7<true>(S, Bx, role);
-        else box7<false>(S, Bx, role);
+        box7_any(S, Bx, role);
 #pragma unroll
         for (int j = 0; j < PXL; ++j) {
             const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());
@@ -410,8 +420,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
     }
 #pragma unroll
     for (int j = 0; j < PXL; ++j) S[j] = A[j] + D[j];
-    if (role.edge_wave) box7<true>(S, Bx, role);
-    else box7<false>(S, Bx, role);
+    box7_any(S, Bx, role);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
         if constexpr (has_pools(MODE)) {

@@ -109,6 +109,11 @@ __device__ __forceinline__ unsigned dpp_from_left(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
+// ... where lane 0, which has no left neighbour, gets `edge` instead
+__device__ __forceinline__ unsigned dpp_from_left_or(unsigned edge, unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
 __device__ __forceinline__ unsigned dpp_from_right(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
