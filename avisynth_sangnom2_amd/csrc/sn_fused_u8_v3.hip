@@ -216,7 +216,8 @@ struct RawLine {
 // rank codes: P4 (and the `minBuf > aaf` arm, same result) 0, P5 1, P3 2, P6 3, P2 4, P7 5, P1 6, P8 7, P0 12
 constexpr unsigned kLutLo = 0x04030303u, kLutHi = 0x06010502u;  // code -> 3 + k; code 12 reads 0x00 = 3 + (-3)
 
-__device__ __forceinline__ void make_raw(RawLine& R, const Raw& q, const WideLine& L)
+template <class LineT>
+__device__ __forceinline__ void make_raw(RawLine& R, const Raw& q, const LineT& L)
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -231,8 +232,8 @@ __device__ __forceinline__ void make_raw(RawLine& R, const Raw& q, const WideLin
     // F[j] = [lo strip, 0, hi strip, 0]: pixels j, j+1 side by side, then the four of a strip into one dword
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const unsigned f01 = L.Fv[4 * g + 0] | (L.Fv[4 * g + 1] << 8), f23 = L.Fv[4 * g + 2] | (L.Fv[4 * g + 3] << 8);  // [lo0 lo1 hi0 hi1]
-        const unsigned b01 = L.Bv[4 * g + 0] | (L.Bv[4 * g + 1] << 8), b23 = L.Bv[4 * g + 2] | (L.Bv[4 * g + 3] << 8);
+        const unsigned f01 = L.F(4 * g + 0) | (L.F(4 * g + 1) << 8), f23 = L.F(4 * g + 2) | (L.F(4 * g + 3) << 8);  // [lo0 lo1 hi0 hi1]
+        const unsigned b01 = L.B(4 * g + 0) | (L.B(4 * g + 1) << 8), b23 = L.B(4 * g + 2) | (L.B(4 * g + 3) << 8);
         R.F[0][g] = __builtin_amdgcn_perm(f23, f01, 0x05040100u);
         R.F[1][g] = __builtin_amdgcn_perm(f23, f01, 0x07060302u);
         R.B[0][g] = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
@@ -261,7 +262,7 @@ __device__ __forceinline__ unsigned interpolate4(const RawLine& c, const RawLine
 
 // rank of buffer BUF in the reference's ladder: P4, P5, P3, P6, P2, P7, P1, P8, P0 -> 1..9
 // ... -> the codes of the byte-domain stage 3 (see RawLine) where that runs
-__host__ __device__ constexpr bool raw_stage3(int mode) { return !has_pools(mode); }
+__host__ __device__ constexpr bool raw_stage3(int) { return true; }
 template <int BUF, int MODE>
 constexpr unsigned rank_of()
 {
@@ -366,18 +367,23 @@ struct RowCtx {  // what a row needs besides the lines
     int slot_c, slot_n;  // byte-domain stage 3: LDS slots of the lines above / below the interpolated one
 };
 
+#ifndef SN_LUMA_WIDE
+#define SN_LUMA_WIDE 0
+#endif
+__host__ __device__ constexpr bool wide_lines(int mode) { return !has_pools(mode) || (mode == kLumaSpill && SN_LUMA_WIDE); }
 template <int MODE>
-using LineOf = typename std::conditional<raw_stage3(MODE), WideLine, Line>::type;
+using LineOf = typename std::conditional<wide_lines(MODE), WideLine, Line>::type;
 
 // S1: the costs of row r+1 come from the lines (n, nn); otherwise they are zero (kPlain /
 // kLumaSpill: row bh is never written) or the previous pass's values (kChroma).
-template <int BUF, int MODE, bool S1>
+// STORE: the smoothed row goes to pool_out (lanes / rows that keep nothing carry an out-of-range voffset).
+template <int BUF, int MODE, bool S1, bool STORE>
 __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const LineOf<MODE>& n, const LineOf<MODE>& nn,
                                             const LaneRole& role, const PoolIO& io, const RowCtx& rc,
                                             PoolIO::RawPair& stale)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
-    if constexpr (MODE == kPlain && S1) {
+    if constexpr ((MODE == kPlain || MODE == kLumaSpill) && S1) {
         // A plane on its own never needs the cost itself: |x - y| = (x -sat y) + (y -sat x), so S = A + U + V and
         // A' = O + U + V are one three-operand add each -- two saturating subtracts and two v_add3 where maximum,
         // minimum, subtract and two adds took five instructions (every one costs the same issue slot here).
@@ -394,9 +400,11 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
 #pragma unroll
         for (int j = 0; j < PXL; ++j) {
             const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());
-            A[j] = add3(pk_lshr4(key), U[j], V[j]);
+            O[j] = pk_lshr4(key);
+            A[j] = add3(O[j], U[j], V[j]);
             kmin[j] = pk_min(kmin[j], key);
         }
+        if constexpr (MODE == kLumaSpill && STORE) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
         return;
     }
     if constexpr (chroma_mode(MODE)) {
@@ -440,13 +448,9 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             kmin[j] = pk_min(kmin[j], key);
         }
     }
-    if constexpr (has_pools(MODE)) {
-        // the luma sweep skips the packing where no lane of the wave stores (rows past the hand-off, waves outside
-        // the cone); the chroma sweep cannot afford the branch (registers) and lets the range check drop the stores
-        if constexpr (MODE != kChromaLast) {
-            if (MODE == kChroma || rc.any_out) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
-        }
-    }
+    // no branch around the packing (a branch inside the buffer steps costs more than it saves, see box7): rows past the
+    // hand-off run a sweep without it (STORE), lanes that keep nothing let the range check drop their stores
+    if constexpr (has_pools(MODE) && MODE != kChromaLast && STORE) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
 }
 
 struct Out {
@@ -463,7 +467,19 @@ struct Out {
 #ifndef SN_PLAIN_RB
 #define SN_PLAIN_RB 9
 #endif
-__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kChromaLast ? 6 : has_pools(mode) ? 3 : mode == kPlain ? SN_PLAIN_RB : 9; }
+#ifndef SN_LUMA_RB
+#define SN_LUMA_RB 9
+#endif
+#ifndef SN_CHROMA_RB
+#define SN_CHROMA_RB 9
+#endif
+#ifndef SN_CHROMALAST_RB
+#define SN_CHROMALAST_RB 9
+#endif
+__host__ __device__ constexpr int reg_buffers(int mode)
+{
+    return mode == kChromaLast ? SN_CHROMALAST_RB : mode == kChroma ? SN_CHROMA_RB : mode == kLumaSpill ? SN_LUMA_RB : mode == kPlain ? SN_PLAIN_RB : 9;
+}
 template <int NT, int RB>
 struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread count NT
     static constexpr int nthreads = NT;
@@ -535,7 +551,7 @@ __device__ __forceinline__ void unpark_line(const Parked<NT, RB>& pk, int tid, L
 }
 
 // S3: the row has an interpolated line (stage 3); kChroma sweeps one extra row without one.
-template <int MODE, bool S1, bool S3, int NT>
+template <int MODE, bool S1, bool S3, bool STORE, int NT>
 __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk, int tid, const LineOf<MODE>& n,
                                         const LineOf<MODE>& nn, const LaneRole& role, unsigned thr_key, const PoolIO& io,
                                         const RowCtx& rc)
@@ -554,11 +570,11 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
         constexpr int B = decltype(buf)::value;
         PoolIO::RawPair& st = (B & 1) ? st1 : st0;
         if constexpr (B < reg_buffers(MODE)) {
-            buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st);
+            buffer_step<B, MODE, S1, STORE>(A[B], kmin, n, nn, role, io, rc, st);
         } else {
             unsigned t[PXL];
             load_A(pk, tid, B, t);
-            buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st);
+            buffer_step<B, MODE, S1, STORE>(t, kmin, n, nn, role, io, rc, st);
             store_A(pk, tid, B, t);
         }
     };
@@ -909,9 +925,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // interpolated line).
     TurnTaking turns;
     turns.init(a.turn_shift);
-    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag) {
+    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag, auto store_tag) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
+        constexpr bool STORE = decltype(store_tag)::value;
         turns.update();
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
@@ -966,7 +983,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             rc.vout_hi = (row_out && in_cone(r, a.cone_out, 1)) ? io.v_out_hi : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any((rc.vout != kOutOfRange) | (rc.vout_hi != kOutOfRange)) ? 1 : 0) != 0;
         }
-        const Out o = row_step<MODE, HAS_NEXT, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
+        const Out o = row_step<MODE, HAS_NEXT, S3, STORE>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S3) put(out_row, o);  // stored at once: nothing is carried into the next row
         out_row += dst_step;
         if constexpr (HAS_NEXT && !raw_stage3(MODE)) park_line(parked, tid, n);  // n is the next row's c
@@ -1041,35 +1058,49 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
                 for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * (NW * 64)] = t[j] & real_mask;
             }
         };
-        // run-up rows (nothing interpolated), then the band's own rows; row nr has no following line pair
+        // run-up rows (nothing interpolated, nothing handed on), then the band's own rows; row nr has no following line pair
         static_assert(!chroma_mode(MODE), "the chroma sweeps of the coupling are not cut (sn_fused_v3_common.h)");
+        using ST = std::integral_constant<bool, MODE == kLumaSpill>;
         int r = r0;
         for (; r < ra; ++r) {
-            step(r, L1, L0, T{}, F{});
+            step(r, L1, L0, T{}, F{}, F{});
             L1 = L0;
         }
         leave_state(0);
         const int own_next = rb < nr ? rb + 1 : nr;
         for (; r < own_next; ++r) {
-            step(r, L1, L0, T{}, T{});
+            step(r, L1, L0, T{}, T{}, ST{});
             L1 = L0;
         }
-        if (rb == nr) step(nr, L1, L0, F{}, T{});
+        if (rb == nr) step(nr, L1, L0, F{}, T{}, ST{});
         if (rb < last) leave_state(1);
     } else {
-        // two rows per trip with the roles of the two line registers swapped, so that no row ends in a copy of a line
-        int r = 1;
-        for (; r + 1 < nr; r += 2) {
-            step(r, L1, L0, T{}, T{});
-            step(r + 1, L0, L1, T{}, T{});
-        }
-        if (r < nr) {
-            step(r, L1, L0, T{}, T{});
-            L1 = L0;
-        }
-        if (nr >= 1) step(nr, L1, L0, F{}, T{});
-        if constexpr (chroma_mode(MODE)) {
-            for (int r = nr + 1; r <= last; ++r) step(r, L1, L0, F{}, F{});
+        // Rows [from, to) with a following line pair: two rows per trip with the roles of the two line registers swapped,
+        // so that no row ends in a copy of a line; afterwards L1 is K[to] again.
+        auto rows = [&](int from, int to, auto store_tag) __attribute__((always_inline)) {
+            int r = from;
+            for (; r + 1 < to; r += 2) {
+                step(r, L1, L0, T{}, T{}, store_tag);
+                step(r + 1, L0, L1, T{}, T{}, store_tag);
+            }
+            if (r < to) {
+                step(r, L1, L0, T{}, T{}, store_tag);
+                L1 = L0;
+            }
+        };
+        if constexpr (MODE == kLumaSpill) {
+            // the rows whose smoothed values a chroma pass can see first, with the hand-off; the rest of the plane without
+            const int split = a.rows_out + 1 < nr ? a.rows_out + 1 : nr;
+            rows(1, split, T{});
+            rows(split, nr, F{});
+            if (nr >= 1) step(nr, L1, L0, F{}, T{}, T{});
+        } else {
+            using ST = std::integral_constant<bool, MODE == kChroma>;
+            rows(1, nr, ST{});
+            if (nr >= 1) step(nr, L1, L0, F{}, T{}, ST{});
+            if constexpr (chroma_mode(MODE)) {
+                for (int r = nr + 1; r <= last; ++r) step(r, L1, L0, F{}, F{}, ST{});
+            }
         }
     }
 
