@@ -370,7 +370,10 @@ struct RowCtx {  // what a row needs besides the lines
 #ifndef SN_LUMA_WIDE
 #define SN_LUMA_WIDE 0
 #endif
-__host__ __device__ constexpr bool wide_lines(int mode) { return !has_pools(mode) || (mode == kLumaSpill && SN_LUMA_WIDE); }
+#ifndef SN_CHROMA_WIDE
+#define SN_CHROMA_WIDE 1
+#endif
+__host__ __device__ constexpr bool wide_lines(int mode) { return !has_pools(mode) || (mode == kLumaSpill && SN_LUMA_WIDE) || (chroma_mode(mode) && SN_CHROMA_WIDE); }
 template <int MODE>
 using LineOf = typename std::conditional<wide_lines(MODE), WideLine, Line>::type;
 
@@ -416,8 +419,26 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (BUF + 2 < kBuffers) stale = io.issue(BUF + 2, rc.r + 1, rc.vin_lo, rc.vin_hi);
         if constexpr (S1) {
+            // No select: where the lines exist (inside the chroma region) the previous pass's row r + 1 is outside the
+            // dependency cone as long as r + 1 <= cone_nr -- every row that has a line pair -- so its load was dropped and
+            // reads zero; where they do not exist the lines read zero and so do their costs.  One of the two is zero
+            // everywhere: S = A + cost + stale and A' = O + cost + stale are three-operand adds.
+            unsigned C[PXL];
 #pragma unroll
-            for (int j = 0; j < PXL; ++j) D[j] = bfi(role.inside_mask, cost<BUF>(n, nn, j), D[j]);
+            for (int j = 0; j < PXL; ++j) {
+                C[j] = cost<BUF>(n, nn, j);
+                S[j] = add3(A[j], C[j], D[j]);
+            }
+            box7_any(S, Bx, role);
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) {
+                const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());
+                O[j] = pk_lshr4(key);
+                A[j] = add3(O[j], C[j], D[j]);
+                kmin[j] = pk_min(kmin[j], key);
+            }
+            if constexpr (MODE != kChromaLast && STORE) io.store(BUF, rc.r, rc.vout, rc.vout_hi, O);
+            return;
         }
     } else if constexpr (MODE == kPadded) {
 #pragma unroll
@@ -431,22 +452,13 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
     box7_any(S, Bx, role);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        if constexpr (has_pools(MODE)) {
-            // the pool-coupled modes sit at the register limit; this form allocates best there
-            const unsigned t = Bx[j] & 0x0ff00ff0u;  // O << 4, shared by O and the key
-            O[j] = t >> 4;                           // (sum / 16) wraps to uint8_t, SangNom2.cpp:152
-            A[j] = O[j] + D[j];                      // O + D[r+1]
-            kmin[j] = pk_min(kmin[j], t | rank_of<BUF, MODE>());
-        } else {
-            // key = (sum / 16 mod 256) << 4 | rank in ONE v_and_or_b32; the rank (< 16) falls off the PACKED shift that
-            // yields O (a 32-bit shift would push the high half's rank into the low half).  With two waves per SIMD
-            // every VALU instruction costs about the same (profiles/r2_ubench_valu_issue_rates.txt), so what counts is
-            // the NUMBER of instructions: 4 here, 5 above.
-            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());
-            O[j] = pk_lshr4(key);
-            A[j] = O[j] + D[j];
-            kmin[j] = pk_min(kmin[j], key);
-        }
+        // key = (sum / 16 mod 256) << 4 | rank in ONE v_and_or_b32; the rank (< 16) falls off the PACKED shift that
+        // yields O (a 32-bit shift would push the high half's rank into the low half).  Every VALU instruction of this
+        // stream costs the same issue slot (profiles/r3_ubench_valu_table.txt), so what counts is their NUMBER.
+        const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());
+        O[j] = pk_lshr4(key);        // (sum / 16) wraps to uint8_t, SangNom2.cpp:152
+        A[j] = O[j] + D[j];          // O + D[r+1]
+        kmin[j] = pk_min(kmin[j], key);
     }
     // no branch around the packing (a branch inside the buffer steps costs more than it saves, see box7): rows past the
     // hand-off run a sweep without it (STORE), lanes that keep nothing let the range check drop their stores
