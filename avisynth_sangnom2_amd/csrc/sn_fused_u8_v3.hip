@@ -676,7 +676,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 // The pool-coupled modes park six buffers' state in LDS and have room for ONE copy of the mailbox only: there a second
 // barrier (before publishing) makes sure every wave has taken the previous refresh out of it.  The other modes keep two
 // copies, alternating, and meet once per refresh.
-__host__ __device__ constexpr int mailbox_copies(int mode) { return (has_pools(mode) && mode != kChromaLast) ? 1 : 2; }
+__host__ __device__ constexpr int mailbox_copies(int) { return 2; }  // (round 2: one copy and a second barrier where six buffers' state lived in LDS)
 template <int NW, int COPIES>
 struct Mailbox {  // [copy][wave 0..NW-1][side][slot][72][2 halves] 16-bit entries in dynamic LDS
     unsigned short* h;
