@@ -94,16 +94,57 @@ def cpu_model() -> str:
     return "unknown CPU"
 
 
-def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
+def cpu_topology() -> dict:
+    """Logical CPUs this process may run on, and the physical cores / sockets behind them (/proc/cpuinfo)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores, sockets = set(), set()
+    try:
+        cpu = phys = core = None
+        for line in list(open("/proc/cpuinfo")) + ["\n"]:
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip():
+                if cpu is not None and cpu in allowed:
+                    cores.add((phys, core))
+                    sockets.add(phys)
+                cpu = phys = core = None
+    except (OSError, ValueError):
+        pass
+    n_cores = len(cores) or len(allowed)
+    quota = None  # CPU time the container may use, in CPUs (cgroup v2 cpu.max / v1 cfs quota); None = unlimited
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = round(q / per, 2) if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    return {"logical_cpus": len(allowed), "physical_cores": n_cores, "sockets": len(sockets) or 1,
+            "smt": len(allowed) > n_cores, "cgroup_cpu_quota": quota}
+
+
+def cpu_baseline(fmt, w, h, kw, seconds_target=7.0):
     """A CPU port of the reference's path timed on this box's host cores, one filter instance per thread (the
-    reference's MT_MULTI_INSTANCE model), bounded sample.  For 8-bit Y clips on an AVX2 host this is
-    oracle/sangnom_vec.c -- the oracle's arithmetic written so that gcc vectorises it, standing in for the
-    reference's opt=1 SSE2 path (which cannot be built here) -- otherwise the scalar oracle."""
+    reference's MT_MULTI_INSTANCE model), bounded sample: every thread filters frames until the time is up.  Two
+    runs: one thread per PHYSICAL core the process may use (`value`, `cores`), and 16 threads (`value_16_threads`, the
+    figure of rounds 1 and 2).  For 8-bit Y clips on an AVX2 host this is oracle/sangnom_vec.c -- the oracle's arithmetic
+    written so that gcc vectorises it, standing in for the reference's opt=1 SSE2 path (which cannot be built here) --
+    otherwise the scalar oracle."""
     from avisynth_sangnom2_amd import clip_format, synth
     from oracle.oracle import Config, Oracle, VecOracleY8, vec_lib
 
     clip = clip_format(fmt, w, h)
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    topo = cpu_topology()
     src = synth.frame(clip, "noise", seed=1)
     vec = fmt == "Y8" and not kw.get("dh") and not kw.get("fresh_pool") and vec_lib() is not None
     if vec:
@@ -120,33 +161,66 @@ def cpu_baseline(fmt, w, h, kw, seconds_target=12.0):
         label = "scalar port (oracle/sangnom_oracle.c)"
     out_h = h * 2 if kw.get("dh") else h
     proto = [np.zeros((out_h >> (clip.subh if p else 0), w >> (clip.subw if p else 0)), dtype=clip.dtype) for p in range(min(clip.planes, 3))]
-    # calibrate on one frame, single thread
+    # single thread, one frame (after a first call that touches the memory)
     o, run = make()
     run(proto)
     t0 = time.perf_counter()
     run(proto)
     one = time.perf_counter() - t0
-    per_thread = min(max(1, int(seconds_target / max(one, 1e-3))), 2048)
-    workers = [make() for _ in range(cores)]
-    dsts = [[d.copy() for d in proto] for _ in range(cores)]
 
-    def work(i):
-        for _ in range(per_thread):
-            workers[i][1](dsts[i])
+    def timed(threads, seconds):
+        workers = [make() for _ in range(threads)]
+        dsts = [[d.copy() for d in proto] for _ in range(threads)]
+        for i in range(threads):
+            workers[i][1](dsts[i])  # first touch outside the timed region
+        done = [0] * threads
+        start = threading.Barrier(threads + 1)
 
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
-    frames = cores * per_thread
-    return {"value": round(frames * w * out_h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "cpu": cpu_model(),
-            "sample": f"{label}: {frames} frames of {fmt} {w}x{h} uniform noise, {cores} threads x {per_thread} frames, "
-                      f"one filter instance per thread ({dt:.1f} s; single-thread {one * 1e3:.0f} ms/frame) on "
-                      f"{os.cpu_count()} logical CPUs of {cpu_model()}"}
+        def work(i):
+            start.wait()
+            end = time.perf_counter() + seconds
+            n = 0
+            while True:
+                workers[i][1](dsts[i])
+                n += 1
+                if time.perf_counter() >= end:
+                    break
+            done[i] = n
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in ths:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        return sum(done), dt
+
+    physical = max(1, topo["physical_cores"])
+    quota = topo["cgroup_cpu_quota"]
+    # The cores this process can really use: one thread per physical core, but no more threads than the container's CPU
+    # quota pays for (the GPU boxes show 2 x 64 cores / 256 logical CPUs under a cgroup quota of 16 CPUs: 128 threads
+    # there are throttled to 16 CPUs' worth of time and thrash the caches -- 2.6 Gpixel/s against 11.2 with 16 threads).
+    cores = physical if quota is None else max(1, min(physical, int(quota + 0.5)))
+    frames, dt = timed(cores, seconds_target)
+    rec = {"value": round(frames * w * out_h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+           "cpu": cpu_model(), "sockets": topo["sockets"], "physical_cores": physical, "logical_cpus": topo["logical_cpus"],
+           "smt": topo["smt"], "cgroup_cpu_quota": quota}
+    note = ""
+    if cores != physical:  # what one thread per physical core gives under the quota, for the record
+        fa, da = timed(physical, 0.4 * seconds_target)
+        rec["value_all_physical_cores"] = round(fa * w * out_h / da / 1e6, 2)
+        note = f"; {physical} threads (one per physical core, throttled by the quota): {fa} frames in {da:.1f} s"
+    if cores > 16:
+        f16, d16 = timed(16, 0.4 * seconds_target)
+        rec["value_16_threads"] = round(f16 * w * out_h / d16 / 1e6, 2)
+        note += f"; 16 threads: {f16} frames in {d16:.1f} s"
+    rec["sample"] = (f"{label}: {frames} frames of {fmt} {w}x{h} uniform noise in {dt:.1f} s, {cores} threads, one filter instance "
+                     f"per thread ({topo['sockets']} socket(s), {physical} physical cores, SMT {'on' if topo['smt'] else 'off'}, "
+                     f"{topo['logical_cpus']} logical CPUs visible, cgroup CPU quota {quota}){note}; single thread "
+                     f"{one * 1e3:.0f} ms/frame; {cpu_model()}")
+    return rec
 
 
 def spawn_ranks(args) -> int:
@@ -195,7 +269,7 @@ def main():
             capi.build()
         while not os.path.exists(capi.LIB_PATH):
             time.sleep(1.0)
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
@@ -206,7 +280,8 @@ def main():
     dev_index = int(os.environ.get("SN_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ  # under torchrun, also with one rank
+    if launched:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -252,7 +327,7 @@ def main():
     alg_bytes = algorithmic_bytes_per_frame(clip, flt, kw) * batch
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
 
     torch.cuda.synchronize(dev)  # inputs were generated on the default stream
@@ -271,7 +346,8 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    own_elapsed = elapsed
+    if launched:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -281,7 +357,14 @@ def main():
     launch_ms = sum(dev_ms) / len(dev_ms)
     info = flt.info()
 
-    joined = dist.get_world_size() if world > 1 else 1  # ranks that really took part
+    joined = dist.get_world_size() if launched else 1  # ranks that really took part
+    # every rank's own figures, so that a straggler shows in the line (the aggregate uses the slowest rank's time)
+    mine = {"rank": rank, "device": dev_index, "frames_per_s": round(batch * args.steps / own_elapsed, 1),
+            "kernel_ms_per_launch": round(launch_ms, 4)}
+    per_rank = [mine]
+    if launched:
+        per_rank = [None] * joined
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         frames_total = batch * args.steps * joined
         mpix = frames_total * w * out_h / elapsed / 1e6
@@ -305,6 +388,13 @@ def main():
         out = {
             "metric": "Mpixels/s", "value": round(mpix, 1), "unit": "Mpixels/s",
             "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
+            "distributed": {"backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if launched else None,
+                            "world_size": joined, "collectives": "barrier before and after the timed steps, max-reduce of the elapsed time"
+                                                                 if launched else None,
+                            "per_rank_frames_per_s": [r["frames_per_s"] for r in per_rank],
+                            "per_rank_kernel_ms": [r["kernel_ms_per_launch"] for r in per_rank],
+                            "min_rank_frames_per_s": min(r["frames_per_s"] for r in per_rank),
+                            "max_rank_frames_per_s": max(r["frames_per_s"] for r in per_rank)},
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": {1: "u8", 2: "u16", 4: "f32"}[clip.bytes],
             "data": "synthetic",
@@ -340,7 +430,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(fmt, w, h, kw)
         print(json.dumps(out), flush=True)
     flt.close()
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 
