@@ -25,7 +25,14 @@ EXPORTS = (
     "sn_host_slots", "sn_submit_host", "sn_collect_host", "sn_turn_device",
     "sn_aa_create", "sn_aa_process_host", "sn_aa_last_error", "sn_aa_destroy",
     "sn_pin_host_buffer", "sn_unpin_host_buffer", "sn_submit_host_to", "sn_debug_set_bands",
+    "sn_create_with_policy", "sn_get_policy", "sn_set_policy", "sn_aa_create_with_policy",
 )
+
+SN_SMALL_AUTO, SN_SMALL_SWEEP = 0, 1
+# What a filter object asks for when its caller says nothing (all zeros = the library's defaults).  The test suite
+# changes entries here (small clips would otherwise never reach the whole-plane sweeps); the library itself reads no
+# environment variable.
+POLICY_DEFAULTS = {"small_launches": SN_SMALL_AUTO, "chain": 0, "copy_threads": 0, "scratch_budget_mb": 0}
 
 
 class SnConfig(ctypes.Structure):
@@ -33,6 +40,18 @@ class SnConfig(ctypes.Structure):
         "struct_size", "width", "height", "bytes_per_sample", "bits_per_sample", "num_planes",
         "sub_w", "sub_h", "order", "aa", "aac", "dh", "luma", "chroma", "device", "max_batch",
         "mode", "host_depth", "isolated_planes", "fresh_pool")] + [("stream", ctypes.c_void_p)]
+
+
+class SnPolicy(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("struct_size", "small_launches", "chain", "copy_threads", "scratch_budget_mb")] + [
+        ("reserved", ctypes.c_int32 * 3)]
+
+
+def policy(**over) -> "SnPolicy":
+    """sn_policy from POLICY_DEFAULTS with the given fields replaced (None = keep the default)."""
+    v = dict(POLICY_DEFAULTS)
+    v.update({k: x for k, x in over.items() if x is not None})
+    return SnPolicy(struct_size=ctypes.sizeof(SnPolicy), **{k: int(x) for k, x in v.items()})
 
 
 class SnInfo(ctypes.Structure):
@@ -89,6 +108,10 @@ def load():
     L.sn_abi_version.restype = ctypes.c_int
     L.sn_validate.argtypes = [ctypes.POINTER(SnConfig), ctypes.c_char_p, ctypes.c_size_t]
     L.sn_create.argtypes = [ctypes.POINTER(SnConfig), ctypes.POINTER(vp)]
+    L.sn_create_with_policy.argtypes = [ctypes.POINTER(SnConfig), ctypes.POINTER(SnPolicy), ctypes.POINTER(vp)]
+    L.sn_get_policy.argtypes = [vp, ctypes.POINTER(SnPolicy)]
+    L.sn_set_policy.argtypes = [vp, ctypes.POINTER(SnPolicy)]
+    L.sn_aa_create_with_policy.argtypes = [ctypes.POINTER(SnConfig), ctypes.POINTER(SnPolicy), ctypes.POINTER(vp)]
     L.sn_destroy.argtypes = [vp]
     L.sn_destroy.restype = None
     L.sn_last_error.argtypes = [vp]

@@ -21,6 +21,7 @@ namespace sn {
 
 struct Context {
     sn_config cfg{};
+    sn_policy policy{};  // zeros = defaults (sangnom_hip.h)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -330,12 +331,31 @@ void sn_destroy(sn_context* h)
     delete c;
 }
 
-// Device scratch one context may hold per kind (pool-path slots; hand-off pools of the fused 4:2:0 sweeps).
-// SN_SCRATCH_BUDGET_MB overrides it (the tests use that to exercise the chunking on small batches).
-static int64_t scratch_budget()
+// Environment overrides of the policy exist only in builds with -DSN_TEST_HOOKS (bisecting in the field); the shipped
+// library reads no environment variable.
+static const char* test_env(const char* name)
 {
-    const char* e = getenv("SN_SCRATCH_BUDGET_MB");
-    return e && atoll(e) > 0 ? atoll(e) << 20 : 24ll << 30;
+#ifdef SN_TEST_HOOKS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+// Device scratch one context may hold per kind (pool-path slots; hand-off pools of the fused 4:2:0 sweeps):
+// sn_policy.scratch_budget_mb, 24 GiB by default (the tests shrink it to exercise the chunking on small batches).
+static int64_t scratch_budget(const Context* c)
+{
+    if (const char* e = test_env("SN_SCRATCH_BUDGET_MB"))
+        if (atoll(e) > 0) return atoll(e) << 20;
+    return c->policy.scratch_budget_mb > 0 ? (int64_t)c->policy.scratch_budget_mb << 20 : 24ll << 30;
+}
+static bool scratch_budget_is_default(const Context* c) { return c->policy.scratch_budget_mb <= 0 && !test_env("SN_SCRATCH_BUDGET_MB"); }
+static bool sweeps_always(const Context* c)  // SN_SMALL_SWEEP
+{
+    if (const char* e = test_env("SN_PREFER_POOL")) return atoi(e) == 0;
+    return c->policy.small_launches == SN_SMALL_SWEEP;
 }
 
 // The pool: zero-filled (the convention that makes the reference's output defined).
@@ -423,7 +443,7 @@ static int create_impl(const sn_config* cfg, Context* c)
     c->pool.slot_bytes = (c->pool.slot_bytes + 255) & ~(int64_t)255;
     int rc = SN_OK;
     auto fit = [&](int64_t per_frame) {
-        const int64_t n = scratch_budget() / per_frame;
+        const int64_t n = scratch_budget(c) / per_frame;
         const int64_t want = c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth;  // frames in flight
         return (int)(n < 1 ? 1 : n < want ? n : want);
     };
@@ -457,7 +477,7 @@ static int create_impl(const sn_config* cfg, Context* c)
                                                     : sn::fused_v3_waves(cfg->width);
         const int round = 256 * (8 / nw);
         c->fslots = fit(2 * c->fpool_frame_bytes);  // fused420 implies history-free (fused_eligible)
-        if (c->fslots < round && !getenv("SN_SCRATCH_BUDGET_MB")) {
+        if (c->fslots < round && scratch_budget_is_default(c)) {
             // wide float frames: a chunk below one round leaves compute units idle in every launch, so the hand-off
             // pools may take up to a quarter of the device's memory to reach one
             size_t free_b = 0, total_b = 0;
@@ -479,15 +499,31 @@ static int create_impl(const sn_config* cfg, Context* c)
     return SN_OK;
 }
 
-int sn_create(const sn_config* cfg, sn_context** out)
+static const char* policy_text(const sn_policy* p)
+{
+    if (!p) return nullptr;
+    if (p->struct_size != (int32_t)sizeof(sn_policy)) return "sn_policy.struct_size mismatch";
+    if (p->small_launches != SN_SMALL_AUTO && p->small_launches != SN_SMALL_SWEEP) return "sn_policy.small_launches must be SN_SMALL_AUTO or SN_SMALL_SWEEP";
+    if (p->chain != 0 && p->chain != -1) return "sn_policy.chain must be 0 (on) or -1 (off)";
+    if (p->copy_threads < 0 || p->copy_threads > 16) return "sn_policy.copy_threads must be 0..16";
+    if (p->scratch_budget_mb < 0) return "sn_policy.scratch_budget_mb must not be negative";
+    return nullptr;
+}
+
+int sn_create(const sn_config* cfg, sn_context** out) { return sn_create_with_policy(cfg, nullptr, out); }
+
+int sn_create_with_policy(const sn_config* cfg, const sn_policy* policy, sn_context** out)
 {
     if (!cfg || !out) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "cfg / out is NULL");
     *out = nullptr;
     char msg[256];
     int rc = sn_validate(cfg, msg, sizeof msg);
     if (rc != SN_OK) return rc;  // g_last_error already holds the text
+    if (const char* t = policy_text(policy)) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "%s", t);
     Context* c = new (std::nothrow) Context();
     if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "out of host memory");
+    if (policy) c->policy = *policy;
+    c->policy.struct_size = (int32_t)sizeof(sn_policy);
     rc = create_impl(cfg, c);
     if (rc != SN_OK) {
         sn::g_last_error = c->err;
@@ -520,13 +556,14 @@ static KeptLines kept_lines(const Context* c, int p, int parity)
     return {field_offset(c, parity), 2, c->plane_h_out(p) / 2};
 }
 
-// The host's copy threads (staging of the ring, kept lines of the synchronous call): SN_COPY_THREADS in all, the caller included.
+// The host's copy threads (staging of the ring, kept lines of the synchronous call): sn_policy.copy_threads in all, the caller included.
 static void ensure_copier(Context* c)
 {
     if (c->copier) return;
-    const char* e = getenv("SN_COPY_THREADS");
+    const char* e = test_env("SN_COPY_THREADS");
     const unsigned hw = std::thread::hardware_concurrency();
-    int workers = e ? atoi(e) - 1 : (hw >= 8 ? 3 : hw >= 4 ? 1 : 0);
+    const int asked = e ? atoi(e) : c->policy.copy_threads;  // in all, the caller included; 0 = by core count
+    int workers = asked > 0 ? asked - 1 : (hw >= 8 ? 3 : hw >= 4 ? 1 : 0);
     if (workers < 0) workers = 0;
     if (workers > 15) workers = 15;
     c->copier = new Copier(workers);
@@ -578,8 +615,7 @@ static int check_planes(Context* c, const void* const src[3], const int32_t sp[3
 static bool prefer_pool(const Context* c, int n, int slot0)
 {
     if (c->cfg.mode != SN_MODE_AUTO || !c->history_free || slot0 + n > c->slots) return false;
-    if (const char* e = getenv("SN_PREFER_POOL"))  // 0: always sweep (the tests use it to reach the sweeps with small clips)
-        if (atoi(e) == 0) return false;
+    if (sweeps_always(c)) return false;  // SN_SMALL_SWEEP (the tests use it to reach the sweeps with small clips)
     const int B = c->cfg.bytes_per_sample;
     const double t_row = B == 1 ? 3.5e-6 : B == 2 ? 4.05e-6 : 5.7e-6;     // fused sweep, per row
     const double per_elem = B == 1 ? 14.7e-12 : B == 2 ? 20e-12 : 32.5e-12;  // pool path, per pool element and frame
@@ -634,9 +670,7 @@ static int band_count(Context* c, int n, int slot0)
     const int nr_min = band_rows_available(c);
     if (nr_min == 0) return 0;
     if (slot0 + n > c->slots || slot0 + n > kMaxBandSlots) return 0;  // the fallback needs the frames' pool slots
-    if (c->band_force == 0)
-        if (const char* e = getenv("SN_PREFER_POOL"))  // 0: whole-plane sweeps always (see prefer_pool)
-            if (atoi(e) == 0) return 0;
+    if (c->band_force == 0 && sweeps_always(c)) return 0;  // whole-plane sweeps always (see prefer_pool)
     int nb = c->band_force > 0 ? c->band_force : 512 / n;  // about two workgroups per CU in all
     if (nb > nr_min / kMinBandRows) nb = nr_min / kMinBandRows;
     if (nb > kMaxBands) nb = kMaxBands;
@@ -704,9 +738,27 @@ static int ensure_bands(Context* c)
 // call queues its copies from pageable host memory -- allocating in the middle of such a call (as the lazy
 // ensure_pool / ensure_bands of run_group would) puts hipMalloc / hipHostMalloc between the runtime's in-flight staging
 // of those copies and their completion.
+static int chain_planes(const Context* c, int planes[3]);
+static int ensure_chain(Context* c, int pn, hipStream_t st);
+
 static int prepare_small_launch_scratch(Context* c)
 {
-    if (c->cfg.mode != SN_MODE_AUTO || !c->history_free) return SN_OK;
+    if (!c->history_free) {
+        // a history-carrying clip: even ONE frame with two processed planes is a chain of passes, so the chain's ring is
+        // part of what the host-facing calls need -- allocated here, before their copies are queued, not by the first
+        // chained launch in the middle of a pipelined call.  A ring that cannot be had leaves the
+        // context on the pass-by-pass path (chain_slots = -1), as run_chain's own fallback does.
+        int planes[3];
+        const int pn = chain_planes(c, planes);
+        if (pn > 0) {
+            const int rc = ensure_pool(c);
+            if (rc != SN_OK) return rc;
+            (void)ensure_chain(c, pn, c->stream);
+            SN_HIP(c, hipStreamSynchronize(c->stream));  // the ring's first user may be a ring slot's stream
+        }
+        return SN_OK;
+    }
+    if (c->cfg.mode != SN_MODE_AUTO) return SN_OK;
     int rc = SN_OK;
     if (c->isolated) {
         for (int p = 0; p < c->nplanes() && rc == SN_OK; ++p)
@@ -908,6 +960,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
             SN_HIP(c, sn::launch_pool_plane(st, pa[p], pool, B, c->threshold(p), n, slot0));
             SN_HIP(c, plane_out(p));
         }
+        c->fused_frames += n;  // (luma through the sweeps; banded_frames counts a subset of fused_frames, sangnom_hip.h)
         c->banded_frames += n;
         return SN_OK;
     }
@@ -1013,7 +1066,8 @@ static int chain_planes(const Context* c, int planes[3])
     if (c->chain_slots < 0) return 0;
     if (c->history_free || c->isolated || c->cfg.mode == SN_MODE_FUSED) return 0;
     if (sn::pool_chain_lanes(c->cfg.bytes_per_sample, c->stride_e) < 2 || c->bh < 2) return 0;
-    if (const char* e = getenv("SN_CHAIN"))
+    if (c->policy.chain < 0) return 0;
+    if (const char* e = test_env("SN_CHAIN"))
         if (atoi(e) == 0) return 0;
     int pn = 0;
     for (int p = 0; p < c->nplanes(); ++p) {
@@ -1024,6 +1078,29 @@ static int chain_planes(const Context* c, int planes[3])
     return pn;
 }
 
+// The chain's ring of pool slots: one per pass in flight, sized for the launches this context can see (max_batch or the
+// host ring's depth, at most an eighth of the scratch budget; a synchronous single-frame user gets 2 * pn + 1 slots).
+static int ensure_chain(Context* c, int pn, hipStream_t st)
+{
+    if (c->chain_slots < 0) return SN_CHAIN_UNAVAILABLE;
+    if (c->chain_base) return SN_OK;
+    int64_t fit = scratch_budget(c) / 8 / c->pool.slot_bytes;  // passes per launch
+    const int64_t want = (int64_t)(c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth) * pn;
+    fit = fit > want ? want : fit;
+    fit = fit > 1536 ? 1536 : fit;
+    if (fit < 2 * pn) fit = 2 * pn;
+    c->chain_slots = (int)fit + 1;
+    if (hipMalloc(reinterpret_cast<void**>(&c->chain_base), (size_t)c->pool.slot_bytes * c->chain_slots) != hipSuccess) {
+        (void)hipGetLastError();  // no room for the ring: this context keeps the frame-by-frame path
+        c->chain_base = nullptr;
+        c->chain_slots = -1;
+        return SN_CHAIN_UNAVAILABLE;
+    }
+    SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
+    c->chain_origin = 0;
+    return SN_OK;
+}
+
 static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3], const int64_t sfs[3], const int32_t sp[3],
                      void* const dst[3], const int64_t dfs[3], const int32_t dp[3], int f0, int offset, const int planes[3], int pn)
 {
@@ -1031,22 +1108,8 @@ static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3]
     int rc = ensure_pool(c);
     if (rc != SN_OK) return rc;
     const int B = c->cfg.bytes_per_sample;
-    if (!c->chain_base) {
-        int64_t fit = scratch_budget() / 8 / c->pool.slot_bytes;  // passes per launch
-        const int64_t want = (int64_t)(c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth) * pn;
-        fit = fit > want ? want : fit;
-        fit = fit > 1536 ? 1536 : fit;
-        if (fit < 2 * pn) fit = 2 * pn;
-        c->chain_slots = (int)fit + 1;
-        if (hipMalloc(reinterpret_cast<void**>(&c->chain_base), (size_t)c->pool.slot_bytes * c->chain_slots) != hipSuccess) {
-            (void)hipGetLastError();  // no room for the ring: this context keeps the frame-by-frame path
-            c->chain_base = nullptr;
-            c->chain_slots = -1;
-            return SN_CHAIN_UNAVAILABLE;
-        }
-        SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
-        c->chain_origin = 0;
-    }
+    rc = ensure_chain(c, pn, st);  // (the host-facing entry points have done this before queueing their copies)
+    if (rc != SN_OK) return rc;
     sn::PlaneArgs pa[3];
     for (int p = 0; p < c->nplanes(); ++p) {
         if (c->gate.on && !c->gate.waited[p]) {  // sn_process_host's plane pipeline: the chain needs every plane's copy
@@ -1322,9 +1385,9 @@ static int launch_ring_group(Context* c, int gi)
                 if ((c->cfg.dh || c->process[p]) && nr > 0)
                     SN_HIP(c, hipMemcpy2DAsync(to + (int64_t)(off + 1) * to_pitch, (size_t)2 * to_pitch, from + (int64_t)(off + 1) * c->ring_pitch_out[p],
                                                (size_t)2 * c->ring_pitch_out[p], (size_t)c->plane_w(p) * B, nr, hipMemcpyDeviceToHost, g.stream));
-            } else if (to_pitch == c->ring_pitch_out[p]) {  // same pitch on both sides: one linear transfer
+            } else if (!sd.direct[p]) {  // the context's own staging (same pitch on both sides, padding its own): one linear transfer
                 SN_HIP(c, hipMemcpyAsync(to, from, (size_t)c->ring_bytes_out[p] - (c->ring_pitch_out[p] - c->plane_w(p) * B), hipMemcpyDeviceToHost, g.stream));
-            } else {  // the caller's pinned plane, row by row
+            } else {  // the caller's pinned plane, row by row: the bytes between its rows are not ours to write
                 SN_HIP(c, hipMemcpy2DAsync(to, to_pitch, from, c->ring_pitch_out[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyDeviceToHost, g.stream));
             }
         }
@@ -1469,15 +1532,7 @@ int sn_collect_host(sn_context* h, int32_t slot, void* const dst_arg[3], const i
             SN_HIP(c, hipMemcpy2D(dst[p], dp[p], sd.ptr[p], sd.pitch[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyHostToHost));
             continue;
         }
-        if (sd.kept_on_host) {  // the staging holds the interpolated lines only; the kept ones went to the announced planes at submission
-            const int off = field_offset(c, c->slot_parity[slot]), nr = c->plane_h_out(p) / 2 - 1;
-            if (dst[p] != sd.ptr[p])  // ... which is not where the frame is collected: take them from there
-                SN_HIP(c, hipMemcpy2D(dst[p], dp[p], sd.ptr[p], sd.pitch[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyHostToHost));
-            if ((c->cfg.dh || c->process[p]) && nr > 0)
-                jobs[njobs++] = {static_cast<uint8_t*>(dst[p]) + (size_t)(off + 1) * dp[p], from + (size_t)(off + 1) * c->ring_pitch_out[p], 2 * dp[p],
-                                 2 * c->ring_pitch_out[p], c->plane_w(p) * B, nr};
-            continue;
-        }
+        // (sd.kept_on_host implies direct[p] for every plane: handled above)
         jobs[njobs++] = {static_cast<uint8_t*>(dst[p]), from, dp[p], c->ring_pitch_out[p], c->plane_w(p) * B, c->plane_h_out(p)};
     }
     if (njobs) c->copier->run(jobs, njobs);
@@ -1509,7 +1564,17 @@ int sn_unpin_host_buffer(void* ptr)
             }
         if (!found) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "sn_unpin_host_buffer: not pinned through sn_pin_host_buffer");
     }
-    (void)hipDeviceSynchronize();  // nothing of this process may still be moving data through the mapping
+    // Nothing of this process may still be moving data through the mapping: the registry is process-wide and the
+    // buffers are registered portable, so a context on ANY device may have a transfer in flight on a stream of its own.
+    int ndev = 0, cur = 0;
+    if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess) {
+        for (int d = 0; d < ndev; ++d)
+            if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+        (void)hipSetDevice(cur);
+    } else {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+    }
     const hipError_t e = hipHostUnregister(ptr);
     if (e != hipSuccess) return sn::fail(nullptr, SN_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
     return SN_OK;
@@ -1595,6 +1660,27 @@ int sn_debug_read_pool(sn_context* h, int32_t slot, void* host_dst, size_t bytes
     return SN_OK;
 }
 
+int sn_get_policy(sn_context* h, sn_policy* policy)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (!policy || policy->struct_size != (int32_t)sizeof(sn_policy)) return sn::fail(c, SN_ERR_INVALID_ARG, "sn_policy.struct_size mismatch");
+    *policy = c->policy;
+    return SN_OK;
+}
+
+int sn_set_policy(sn_context* h, const sn_policy* policy)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (!policy) return sn::fail(c, SN_ERR_INVALID_ARG, "policy is NULL");
+    if (const char* t = policy_text(policy)) return sn::fail(c, SN_ERR_INVALID_ARG, "%s", t);
+    c->policy.small_launches = policy->small_launches;
+    c->policy.chain = policy->chain;
+    c->policy.copy_threads = policy->copy_threads;  // (a copier that already runs keeps its threads)
+    return SN_OK;
+}
+
 int sn_debug_set_bands(sn_context* h, int32_t bands, int32_t warm_rows)
 {
     Context* c = reinterpret_cast<Context*>(h);
@@ -1656,7 +1742,9 @@ void sn_aa_destroy(sn_aa_context* a)
     delete a;
 }
 
-int sn_aa_create(const sn_config* cfg, sn_aa_context** out)
+int sn_aa_create(const sn_config* cfg, sn_aa_context** out) { return sn_aa_create_with_policy(cfg, nullptr, out); }
+
+int sn_aa_create_with_policy(const sn_config* cfg, const sn_policy* policy, sn_aa_context** out)
 {
     auto fail_aa = [](sn_aa_context* a, int code, const std::string& msg) {
         g_aa_error = msg;
@@ -1678,13 +1766,13 @@ int sn_aa_create(const sn_config* cfg, sn_aa_context** out)
     c1.max_batch = 1;
     c1.mode = SN_MODE_AUTO;
     c1.stream = nullptr;
-    int rc = sn_create(&c1, &a->first);
+    int rc = sn_create_with_policy(&c1, policy, &a->first);
     if (rc != SN_OK) return fail_aa(a, rc, sn_last_error(nullptr));
     sn_config c2 = *cfg;
     c2.max_batch = 1;
     c2.mode = SN_MODE_AUTO;
     c2.stream = sn_get_stream(a->first);
-    rc = sn_create(&c2, &a->second);
+    rc = sn_create_with_policy(&c2, policy, &a->second);
     if (rc != SN_OK) return fail_aa(a, rc, sn_last_error(nullptr));
     a->stream = reinterpret_cast<hipStream_t>(sn_get_stream(a->first));
     a->planes = cfg->num_planes < 3 ? cfg->num_planes : 3;

@@ -65,7 +65,9 @@ class SangNom2:
     def __init__(self, clip: ClipFormat, order: int = 1, aa: int = 48, aac: int = 0, threads: int = 0,
                  dh: bool = False, luma: bool = True, chroma: bool = True, opt: int = -1,
                  device: int = 0, max_batch: int = 1, mode: str = "auto", stream: int | None = None,
-                 host_depth: int = 0, isolated_planes: bool = False, fresh_pool: bool = False):
+                 host_depth: int = 0, isolated_planes: bool = False, fresh_pool: bool = False,
+                 small_launches: int | None = None, chain: int | None = None, copy_threads: int | None = None,
+                 scratch_budget_mb: int | None = None):
         # `threads` is a dummy in the reference (README.md:40-41); `opt` picks its CPU code path.
         if opt < -1 or opt > 1:
             raise SangNomError(capi.SN_ERR_CONFIG, "SangNom2: opt must be between -1..2.")  # sic, SangNom2.cpp:420
@@ -81,7 +83,9 @@ class SangNom2:
         self.max_batch = max_batch
         self.device = device
         self._h = ctypes.c_void_p()
-        rc = self._lib.sn_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        # scheduling only (sn_policy, sangnom_hip.h); None = capi.POLICY_DEFAULTS
+        pol = capi.policy(small_launches=small_launches, chain=chain, copy_threads=copy_threads, scratch_budget_mb=scratch_budget_mb)
+        rc = self._lib.sn_create_with_policy(ctypes.byref(cfg), ctypes.byref(pol), ctypes.byref(self._h))
         if rc != capi.SN_OK:
             self._h = None
             raise SangNomError(rc, self._lib.sn_last_error(None).decode())
@@ -136,6 +140,19 @@ class SangNom2:
         out = np.empty((9, i.pool_rows, i.pool_stride), dtype=self.clip.dtype)
         self._check(self._lib.sn_debug_read_pool(self._h, slot, out.ctypes.data, out.nbytes))
         return out
+
+    def set_policy(self, **fields) -> None:
+        """Change the scheduling policy of the live context (sn_set_policy): small_launches, chain, copy_threads."""
+        cur = capi.SnPolicy(struct_size=ctypes.sizeof(capi.SnPolicy))
+        self._check(self._lib.sn_get_policy(self._h, ctypes.byref(cur)))
+        for k, v in fields.items():
+            setattr(cur, k, int(v))
+        self._check(self._lib.sn_set_policy(self._h, ctypes.byref(cur)))
+
+    def get_policy(self) -> capi.SnPolicy:
+        cur = capi.SnPolicy(struct_size=ctypes.sizeof(capi.SnPolicy))
+        self._check(self._lib.sn_get_policy(self._h, ctypes.byref(cur)))
+        return cur
 
     def set_bands(self, bands: int = 0, warm_rows: int = 0) -> None:
         """Test hook: row bands of the small-launch path (sn_debug_set_bands)."""
@@ -325,7 +342,7 @@ class SangNomAAHost:
     SangNomAA (host/sangnom2_avs_plugin.cpp) binds."""
 
     def __init__(self, clip: ClipFormat, order: int = 1, aa: int = 48, aac: int = 0, luma: bool = True, chroma: bool = True,
-                 device: int = 0, isolated_planes: bool = False, fresh_pool: bool = False):
+                 device: int = 0, isolated_planes: bool = False, fresh_pool: bool = False, **policy_kw):
         self.clip = clip
         self._lib = capi.load()
         cfg = capi.SnConfig(
@@ -334,7 +351,8 @@ class SangNomAAHost:
             dh=0, luma=int(luma), chroma=int(chroma), device=device, max_batch=1, mode=capi.SN_MODE_AUTO, host_depth=0,
             isolated_planes=int(isolated_planes), fresh_pool=int(fresh_pool), stream=None)
         self._h = ctypes.c_void_p()
-        rc = self._lib.sn_aa_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        pol = capi.policy(**{k: policy_kw.get(k) for k in ("small_launches", "chain", "copy_threads", "scratch_budget_mb")})
+        rc = self._lib.sn_aa_create_with_policy(ctypes.byref(cfg), ctypes.byref(pol), ctypes.byref(self._h))
         if rc != capi.SN_OK:
             self._h = None
             raise SangNomError(rc, self._lib.sn_aa_last_error(None).decode())

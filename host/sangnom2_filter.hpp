@@ -38,6 +38,7 @@ struct Args {  // SangNom2(clip, order, aa, aac, threads, dh, luma, chroma, opt)
     int lookahead = -1;  // frames in flight behind GetFrame; -1: $SANGNOM_LOOKAHEAD or 1 (synchronous)
     bool isolated = false;  // extension: every plane filtered as a Y clip of its own (sn_config.isolated_planes)
     bool fresh = false;     // extension: ... and every frame by a new instance (sn_config.fresh_pool)
+    sn_policy policy{};     // scheduling only (sangnom_hip.h); zeros = the defaults
 };
 
 template <class Host>
@@ -88,7 +89,9 @@ public:
         c.host_depth = std::max(1, std::min(la, 256));
         c.isolated_planes = a.isolated ? 1 : 0;
         c.fresh_pool = a.fresh ? 1 : 0;
-        const int rc = sn_create(&c, &ctx_);
+        sn_policy pol = a.policy;
+        pol.struct_size = (int32_t)sizeof pol;
+        const int rc = sn_create_with_policy(&c, &pol, &ctx_);
         if (rc != SN_OK) env->ThrowError("%s: %s", name, sn_last_error(nullptr));
         if (a.dh) Host::SetHeight(vi_, Host::Height(vi_) * 2);  // src/SangNom2.cpp:284-285
         planes_ = c.num_planes;
@@ -196,7 +199,8 @@ private:
             const int parity = args_.order == 0 ? (Host::GetParity(child_, p.n) ? 1 : 0) : 1;
             if (sn_submit_host(ctx_, sp, spitch, parity, &p.slot) != SN_OK) env->ThrowError("SangNom2: %s", sn_last_error(ctx_));
             CopyAlpha(p.src, p.dst);
-            p.src = FramePtr();
+            // p.src stays referenced until the slot is collected: a source plane that lies in pinned memory is read by
+            // the device straight from the host's frame, asynchronously (sn_submit_host, sangnom_hip.h)
             inflight_.push_back(p);
         }
         if (inflight_.empty()) env->ThrowError("SangNom2: frame %d is outside the clip", n);
@@ -254,7 +258,9 @@ public:
         c.max_batch = 1;
         c.isolated_planes = a.isolated ? 1 : 0;
         c.fresh_pool = a.fresh ? 1 : 0;
-        if (sn_aa_create(&c, &ctx_) != SN_OK) env->ThrowError("%s: %s", name, sn_aa_last_error(nullptr));
+        sn_policy pol = a.policy;
+        pol.struct_size = (int32_t)sizeof pol;
+        if (sn_aa_create_with_policy(&c, &pol, &ctx_) != SN_OK) env->ThrowError("%s: %s", name, sn_aa_last_error(nullptr));
         planes_ = c.num_planes;
         alpha_ = Host::NumComponents(vi_) == 4;
     }

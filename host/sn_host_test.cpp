@@ -63,6 +63,9 @@ int main(int argc, char** argv)
     a.chroma = h[12] != 0;
     const int nframes = h[13];
     clip->vi.num_frames = nframes;
+    // the test clips are small: SN_HOST_TEST_SWEEPS=1 (read by this TEST program, the library reads no environment) asks
+    // for the whole-plane sweeps instead of the small-launch paths
+    if (const char* e = getenv("SN_HOST_TEST_SWEEPS")) a.policy.small_launches = atoi(e) ? SN_SMALL_SWEEP : SN_SMALL_AUTO;
     const bool aa_idiom = argc > 3 && strcmp(argv[3], "aa") == 0;
     if (argc > 3 && !aa_idiom) a.lookahead = atoi(argv[3]);
     std::vector<int> order;

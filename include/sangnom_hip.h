@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 2
+#define SN_ABI_VERSION 3
 
 typedef struct sn_context sn_context;
 
@@ -91,6 +91,26 @@ typedef struct sn_config {
     void*   stream;           /* hipStream_t to run on; NULL = the context creates its own   */
 } sn_config;
 
+/* Scheduling policy of a context (sn_create_with_policy / sn_set_policy).  Nothing here changes a result -- every path
+ * is exact -- only which kernels run and how much memory they may take.  A zero in any field means "the default".
+ * (Rounds 1-2 read these from environment variables; the library reads none now.  A build with -DSN_TEST_HOOKS still
+ * honours SN_PREFER_POOL, SN_CHAIN, SN_COPY_THREADS and SN_SCRATCH_BUDGET_MB as overrides, for bisecting in the field.) */
+enum {
+    SN_SMALL_AUTO = 0,   /* launches of a few frames (a synchronous GetFrame, a short look-ahead) are cut into row   *
+                          * bands, or go to the pool kernels where the cost model says so        */
+    SN_SMALL_SWEEP = 1   /* whole-plane sweeps whenever the configuration is eligible, whatever the launch size     */
+};
+typedef struct sn_policy {
+    int32_t struct_size;        /* = sizeof(sn_policy)                                                             */
+    int32_t small_launches;     /* SN_SMALL_*                                                                      */
+    int32_t chain;              /* history-carrying clips as chains of passes: 0 = on, -1 = off   */
+    int32_t copy_threads;       /* host threads that stage / copy lines, the caller included; 0 = by core count,   *
+                                 * at most 16.  Takes effect when the context first needs them                      */
+    int32_t scratch_budget_mb;  /* device scratch per kind (pool slots; hand-off pools of the coupled sweeps; the    *
+                                 * chain's ring takes an eighth); 0 = 24576.  Read at creation only                  */
+    int32_t reserved[3];        /* zero                                                                            */
+} sn_policy;
+
 /* Geometry and counters of a live context. */
 typedef struct sn_info {
     int32_t struct_size;
@@ -100,7 +120,8 @@ typedef struct sn_info {
     int32_t fused_eligible;   /* 1 if the fused kernel serves this configuration             */
     int32_t history_free;     /* 1 if a frame's result cannot depend on earlier frames       */
     int64_t frames;           /* frames processed so far                                     */
-    int64_t fused_frames;     /* ... of which by the fused kernel                            */
+    int64_t fused_frames;     /* ... of which by the fused sweeps (a single 4:2:0 frame whose luma *
+                               * ran in row bands and whose chroma ran on the pool kernels counts) */
     int32_t coupled_rows;     /* rows per buffer the fused 4:2:0 sweeps hand from plane to   *
                                * plane (0: this configuration has no such hand-off)          */
     int32_t reserved0;
@@ -120,7 +141,13 @@ int sn_validate(const sn_config* cfg, char* msg, size_t msg_len);
 /* Constructor of the filter instance (src/SangNom2.cpp:275-330): thresholds, pool geometry,
  * device pool (zero-filled), stream.  Runs sn_validate first. */
 int sn_create(const sn_config* cfg, sn_context** out);
+int sn_create_with_policy(const sn_config* cfg, const sn_policy* policy /* NULL = defaults */, sn_context** out);
 void sn_destroy(sn_context* ctx);
+
+/* The policy in force / a new one (small_launches, chain and copy_threads may change during a context's life; the
+ * scratch budget is fixed at creation and ignored here). */
+int sn_get_policy(sn_context* ctx, sn_policy* policy);
+int sn_set_policy(sn_context* ctx, const sn_policy* policy);
 
 /* Text of the last error on this context; with ctx == NULL, of the last failed sn_create /
  * sn_validate on the calling thread.  Never NULL. */
@@ -153,7 +180,7 @@ int sn_process_device_strided(sn_context* ctx, int32_t nframes,
 /* Pipelined host path (what a plugin's GetFrame with look-ahead binds).  The context owns
  * sn_host_slots() frame slots (about cfg.host_depth; fewer if scratch is short), each with pinned staging and
  * device buffers for one source and one output frame.  sn_submit_host copies the source planes into the next
- * slot and queues its H2D without waiting; the slots form up to four groups, and when a group is full (or one
+ * slot (planes in pinned memory are not copied: see "Pinned host frames" below) and queues its H2D without waiting; the slots form up to four groups, and when a group is full (or one
  * of its frames is collected early) one launch sweeps its frames on the group's stream, D2H behind it.
  * sn_collect_host waits for the slot's group and copies the output planes out.  Transfers and sweeps of
  * different groups overlap.  Slots are handed out round-robin, so collecting in submission order never blocks
@@ -174,7 +201,12 @@ int sn_collect_host(sn_context* ctx, int32_t slot, void* const dst[3], const int
  * plane.  When every destination plane of a submission is pinned, the kept lines of the output are copied from src
  * to dst on the host during sn_submit_host_to and only the interpolated lines cross PCIe afterwards: the caller must
  * leave the announced planes alone until the slot is collected (and src, dst must not overlap).  Process-wide
- * registry, thread-safe. */
+ * registry, thread-safe.
+ * LIFETIME OF A PINNED SOURCE: sn_submit_host / sn_submit_host_to do not capture a source plane that lies in pinned
+ * memory -- the transfer reads the caller's memory asynchronously -- so such a plane must stay valid and UNCHANGED
+ * until its slot has been collected (a host that recycles frame buffers keeps the frame referenced until then, as
+ * host/sangnom2_filter.hpp does).  Unpinned source planes are copied into the slot's staging before the call
+ * returns, as ever.  sn_unpin_host_buffer waits for every device's outstanding work before it unregisters. */
 int sn_pin_host_buffer(void* ptr, size_t bytes);
 int sn_unpin_host_buffer(void* ptr);
 int sn_submit_host_to(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3], void* const dst[3],
@@ -199,6 +231,7 @@ int sn_turn_device(sn_context* ctx, int32_t direction, int32_t nframes, const vo
  * function of the reference; host/sangnom2_avs_plugin.cpp registers it as SangNomAA. */
 typedef struct sn_aa_context sn_aa_context;
 int sn_aa_create(const sn_config* cfg, sn_aa_context** out);
+int sn_aa_create_with_policy(const sn_config* cfg, const sn_policy* policy /* NULL = defaults; both passes */, sn_aa_context** out);
 int sn_aa_process_host(sn_aa_context* ctx, const void* const src[3], const int32_t src_pitch[3], void* const dst[3],
                        const int32_t dst_pitch[3], int32_t parity);
 const char* sn_aa_last_error(const sn_aa_context* ctx); /* ctx == NULL: last failed sn_aa_create on this thread */

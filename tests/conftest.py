@@ -27,4 +27,5 @@ def hip_lib():
 def sweeps_always(monkeypatch):
     """In auto mode the library gives launches of a few frames to the pool path (both paths are exact); parity tests
     that mean to exercise the fused sweeps with small clips switch that off."""
-    monkeypatch.setenv("SN_PREFER_POOL", "0")
+    from avisynth_sangnom2_amd import capi
+    monkeypatch.setitem(capi.POLICY_DEFAULTS, "small_launches", capi.SN_SMALL_SWEEP)

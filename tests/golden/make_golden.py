@@ -43,6 +43,11 @@ FULL_SIZE = [
     ("2160p YUV420P16", "YUV420P16", 3840, 2160, dict(aa=48, aac=48), "noise", 1),
     ("2160p-out YUV444PS dh", "YUV444PS", 3840, 1080, dict(aa=48, aac=48, dh=True), "sine", 1),
     ("4320p Y8", "Y8", 7680, 4320, dict(order=1, aa=48), "edges", 1),
+    # round 3: more content for the default single-frame path (row bands / luma bands + pool chroma)
+    ("2160p Y8 noise", "Y8", 3840, 2160, dict(order=1, aa=48), "noise", 1),
+    ("2160p YUV420P8 checker", "YUV420P8", 3840, 2160, dict(aa=48, aac=48), "checker", 1),
+    ("2160p YUV420PS", "YUV420PS", 3840, 2160, dict(aa=48, aac=48), "noise", 1),
+    ("2160p YUV420P16 checker", "YUV420P16", 3840, 2160, dict(aa=48, aac=48), "checker", 1),
 ]
 
 
@@ -83,4 +88,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--hashes-only" in sys.argv:
+        full_size_hashes()
+    else:
+        main()

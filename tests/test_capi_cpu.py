@@ -26,7 +26,23 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(hip_lib, name), f"libsangnom_hip.so does not export {name}"
-    assert hip_lib.sn_abi_version() == 2  # 2: + sn_aa_* (round 2)
+    assert hip_lib.sn_abi_version() == 3  # 2: + sn_aa_* (round 2); 3: + sn_policy (round 3)
+
+
+def test_the_library_reads_no_environment_variable(hip_lib):
+    """Scheduling knobs are part of the ABI (sn_policy); the shipped library has no getenv -- only a -DSN_TEST_HOOKS
+    build does.  And a policy is checked before any device is touched."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms, "libsangnom_hip.so imports getenv"
+    h = ctypes.c_void_p()
+    cfg = _cfg()
+    for bad in (dict(small_launches=7), dict(chain=1), dict(copy_threads=99), dict(scratch_budget_mb=-1)):
+        pol = capi.SnPolicy(struct_size=ctypes.sizeof(capi.SnPolicy), **bad)
+        assert hip_lib.sn_create_with_policy(ctypes.byref(cfg), ctypes.byref(pol), ctypes.byref(h)) == capi.SN_ERR_INVALID_ARG
+        assert b"sn_policy" in hip_lib.sn_last_error(None)
+    pol = capi.SnPolicy(struct_size=4)
+    assert hip_lib.sn_create_with_policy(ctypes.byref(cfg), ctypes.byref(pol), ctypes.byref(h)) == capi.SN_ERR_INVALID_ARG
 
 
 def test_validate_matches_reference_messages(hip_lib):

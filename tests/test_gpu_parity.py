@@ -21,7 +21,8 @@ def _sweeps_unless_asked_otherwise(request, monkeypatch):
     """Auto mode hands launches of a few frames to the pool path; these tests want the fused sweeps wherever a
     configuration is eligible, so that policy is off here except in the tests that are about it."""
     if "small_launch_policy" not in request.keywords:
-        monkeypatch.setenv("SN_PREFER_POOL", "0")
+        from avisynth_sangnom2_amd import capi
+        monkeypatch.setitem(capi.POLICY_DEFAULTS, "small_launches", capi.SN_SMALL_SWEEP)
 
 pytestmark = pytest.mark.gpu
 
@@ -451,7 +452,7 @@ def test_pool_stage2_kernels_match_oracle(hip_lib, fmt, w):
 
 # History-carrying clips, several frames per launch: the passes run as one chain (run_chain, k_smooth_{u8,u16,f32}_chain).
 CHAIN_CASES = [
-    # fmt, w, h, kw, frames, SN_SCRATCH_BUDGET_MB
+    # fmt, w, h, kw, frames, sn_policy.scratch_budget_mb
     ("YUV420P8", 720, 96, dict(aac=48), 12, None),              # two strips, eight passes in flight, three planes a frame
     ("Y8", 1000, 56, dict(aa=20), 10, None),                     # three strips
     ("Y8", 40, 200, dict(order=0), 7, None),                     # one strip, sixteen passes in flight; the field follows the parity
@@ -474,7 +475,8 @@ CHAIN_CASES = [
 def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, kw, N, budget, mode):
     import torch
     if budget:
-        monkeypatch.setenv("SN_SCRATCH_BUDGET_MB", str(budget))
+        from avisynth_sangnom2_amd import capi
+        monkeypatch.setitem(capi.POLICY_DEFAULTS, "scratch_budget_mb", budget)
     clip = clip_format(fmt, w, h)
     frames = make_frames(clip, "noise", N - 1, seed0=5) + [synth.frame(clip, "checker", seed=2)]
     parity = [1] * (N // 2) + [0] + [1] * (N - N // 2 - 1)  # two chains with a single frame of the other field between them
@@ -528,7 +530,8 @@ def test_host_ring_groups_of_a_history_carrying_clip_run_as_chains(hip_lib):
 
 def test_chain_can_be_switched_off(hip_lib, monkeypatch):
     import torch
-    monkeypatch.setenv("SN_CHAIN", "0")
+    from avisynth_sangnom2_amd import capi
+    monkeypatch.setitem(capi.POLICY_DEFAULTS, "chain", -1)
     clip = clip_format("Y8", 1000, 56)
     frames = make_frames(clip, "noise", 4, seed0=5)
     ora = Oracle(oracle_cfg(clip))
@@ -546,9 +549,10 @@ def test_chain_can_be_switched_off(hip_lib, monkeypatch):
 
 @pytest.mark.parametrize("fmt,mode", [("YUV420P8", "fused"), ("YUV420P16", "fused"), ("YUV420P8", "pool"), ("Y16", "pool")])
 def test_batch_larger_than_the_scratch_budget_runs_in_chunks(hip_lib, monkeypatch, fmt, mode):
-    """Scratch is bounded (SN_SCRATCH_BUDGET_MB): a bigger batch is run in chunks on the same slots."""
+    """Scratch is bounded (sn_policy.scratch_budget_mb): a bigger batch is run in chunks on the same slots."""
     import torch
-    monkeypatch.setenv("SN_SCRATCH_BUDGET_MB", "1")
+    from avisynth_sangnom2_amd import capi
+    monkeypatch.setitem(capi.POLICY_DEFAULTS, "scratch_budget_mb", 1)
     clip = clip_format(fmt, 256, 64)
     kw = dict(aa=48, aac=48)
     N = 31
@@ -792,6 +796,27 @@ def test_full_size_outputs_have_the_committed_sha256(hip_lib, case):
                 assert hashlib.sha256(np.ascontiguousarray(got[p]).tobytes()).hexdigest() == digest, f"frame {f} plane {p}"
 
 
+@pytest.mark.small_launch_policy
+@pytest.mark.parametrize("case", _FULL_HASHES, ids=[c["name"] for c in _FULL_HASHES])
+def test_default_single_frame_path_at_full_size_has_the_committed_sha256(hip_lib, case, record_property):
+    """What a plugin user gets by default -- ONE frame per call, mode "auto", the library's own small-launch policy:
+    row bands for planes on their own, luma bands + pool kernels for the chroma of 4:2:0 -- at BASELINE's
+    sizes against the committed hashes (src/SangNom2.cpp:332-397 is what both sides compute).  The bands must actually
+    have run; frames redone by the fallback are reported, not forbidden (the result is exact either way)."""
+    import hashlib
+    clip = clip_format(case["fmt"], case["width"], case["height"])
+    with SangNom2(clip, mode="auto", **case["kw"]) as flt:
+        for f, want in enumerate(case["sha256"]):
+            got = flt.get_frame(synth.frame(clip, case["pattern"], seed=case["seed0"] + f), parity=1)
+            for p, digest in enumerate(want):
+                assert hashlib.sha256(np.ascontiguousarray(got[p]).tobytes()).hexdigest() == digest, f"frame {f} plane {p}"
+        info = flt.info()
+        record_property("banded_frames", int(info.banded_frames))
+        record_property("band_fallbacks", int(info.band_fallbacks))
+        assert info.banded_frames == len(case["sha256"]), (info.banded_frames, info.band_fallbacks)
+        assert info.band_fallbacks <= info.banded_frames
+
+
 def test_legacy_sangnom_wrapper_and_single_frame_device_entry(hip_lib):
     """SangNom(clip, order, aa): order 0/1/2 = bottom/top/double-rate is remapped to SangNom2's 2/1/0
     (src/SangNom2.cpp:441,463), aac = 0; and sn_process_device (one device-resident frame) on the context's stream."""
@@ -849,10 +874,10 @@ def test_small_launches_take_the_pool_path_or_row_bands_and_large_ones_the_sweep
         torch.cuda.synchronize()
         flt.process_batch([s[:1] for s in src], one)
         flt.synchronize()
-        # a plane on its own: row bands; coupled 4:2:0: the luma plane in bands, chroma by the pool kernels (not counted as
-        # a fused frame); isolated planes of a width the sweeps only serve padded: the pool path
+        # a plane on its own: row bands; coupled 4:2:0: the luma plane in bands, chroma by the pool kernels (banded_frames
+        # is a subset of fused_frames, sangnom_hip.h); isolated planes of a width the sweeps only serve padded: the pool path
         banded = 0 if kw.get("fresh_pool") else 1
-        fused1 = 1 if clip.planes == 1 else 0
+        fused1 = banded
         info = flt.info()
         assert (info.fused_frames, info.banded_frames) == (fused1, banded)
         out = [torch.zeros_like(s) for s in src]
@@ -1062,220 +1087,7 @@ BAND_CASES = [
 ]
 
 
-@pytest.mark.parametrize("fmt,w,h,kw,bands,warm", BAND_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}-b{c[4]}" for c in BAND_CASES])
-@pytest.mark.parametrize("pattern", ["noise", "checker", "edges", "sine"])
-def test_row_bands_match_oracle(hip_lib, monkeypatch, fmt, w, h, kw, bands, warm, pattern):
-    """A frame cut into row bands equals the oracle whatever the content: where the run-up has not forgotten the
-    guessed state the check sends the frame to the pool path."""
-    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
-    clip = clip_format(fmt, w, h)
-    ora = Oracle(oracle_cfg(clip, **kw))
-    with SangNom2(clip, **kw) as flt:
-        flt.set_bands(bands, warm)
-        for f, src in enumerate(make_frames(clip, pattern, 3, seed0=11)):
-            want = ora.process(src, parity=f & 1)
-            got = flt.get_frame(src, parity=f & 1)
-            for p in range(len(want)):
-                assert same(want[p], got[p]), f"{pattern} frame {f} plane {p}: " + describe_diff(want[p], got[p])
-        info = flt.info()
-        if bands > 0:
-            assert info.banded_frames == 3
-        else:  # automatic: after a failed check the following launches skip the bands
-            assert 1 <= info.banded_frames <= 3 and (info.banded_frames == 3 or info.band_fallbacks > 0)
-        if pattern == "noise" and warm == 0:
-            assert info.band_fallbacks == 0  # the default run-up is long enough for noise
-
-
-@pytest.mark.parametrize("fmt,w,h", [("Y8", 512, 300), ("Y8", 3840, 2160), ("Y16", 512, 300), ("Y32", 512, 300)])
-def test_row_bands_that_fail_the_check_are_redone(hip_lib, monkeypatch, fmt, w, h):
-    """A run-up of one row leaves nearly every band with a wrong state: the check must notice and the pool path must
-    repair every such frame."""
-    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
-    clip = clip_format(fmt, w, h)
-    ora = Oracle(oracle_cfg(clip))
-    with SangNom2(clip) as flt:
-        flt.set_bands(16, 1)
-        for f, src in enumerate(make_frames(clip, "noise", 2, seed0=3)):
-            want = ora.process(src)
-            got = flt.get_frame(src)
-            assert same(want[0], got[0]), f"frame {f}: " + describe_diff(want[0], got[0])
-        info = flt.info()
-        assert info.banded_frames == 2 and info.band_fallbacks == 2
-        flt.set_bands(-1, 0)  # bands off: the same frames through the pool path / plain sweep
-        got = flt.get_frame(src)
-        assert same(want[0], got[0])
-        assert flt.info().banded_frames == 2
-
-
-def test_row_bands_pause_after_failed_checks(hip_lib, monkeypatch):
-    """Content on which the run-up does not forget the guessed state (a checkerboard) would pay for the bands and for the
-    pool path every time: after a failed check the next launches skip the bands."""
-    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
-    clip = clip_format("Y8", 512, 400)
-    ora = Oracle(oracle_cfg(clip))
-    src = synth.frame(clip, "checker", seed=2)
-    want = ora.process(src)
-    with SangNom2(clip) as flt:
-        banded = []
-        for f in range(12):
-            got = flt.get_frame(src)
-            assert same(want[0], got[0]), f"frame {f}"
-            banded.append(flt.info().banded_frames)
-        info = flt.info()
-        if info.band_fallbacks:  # the first frame failed its check: the next eight launches skip the bands, then one more try
-            assert banded[0] == banded[8] == 1 and info.banded_frames <= 2
-
-
-@pytest.mark.parametrize("fmt,w,h,kw", [("YUV420P8", 512, 400, dict(aac=48)), ("YUV420P16", 256, 320, dict(aac=48, fresh_pool=True)),
-                                        ("YUV422PS", 256, 256, dict(aac=48))])
-def test_row_bands_serve_isolated_planes(hip_lib, monkeypatch, fmt, w, h, kw):
-    """isolated_planes: every plane is a plane on its own, so single frames are cut into row bands too (4:2:0 included);
-    same bytes as the whole-plane sweeps."""
-    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
-    clip = clip_format(fmt, w, h)
-    frames = make_frames(clip, "noise", 3, seed0=17)
-    with SangNom2(clip, isolated_planes=True, **kw) as flt:
-        got = [flt.get_frame(src, parity=f & 1) for f, src in enumerate(frames)]
-        info = flt.info()
-        assert (info.banded_frames, info.band_fallbacks) == (3, 0)
-    with SangNom2(clip, isolated_planes=True, mode="fused", **kw) as flt:
-        want = [flt.get_frame(src, parity=f & 1) for f, src in enumerate(frames)]
-        assert flt.info().banded_frames == 0
-    for f in range(3):
-        for p in range(3):
-            assert same(want[f][p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
-
-
-@pytest.mark.parametrize("fmt,w,h,kw,n", [("Y8", 512, 300, {}, 5), ("Y8", 64, 200, dict(order=0), 7), ("Y16", 1056, 240, dict(aa=20), 3),
-                                          ("YUV444PS", 256, 200, dict(aac=48), 4), ("YUV420P8", 512, 320, dict(aac=48), 6)])
-def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, h, kw, n):
-    """A launch of a few frames (a host ring group, a short device batch) is cut into bands as well: frames x bands
-    workgroups, one flag per frame.  One of the frames is a checkerboard, which may fail its check on its own."""
-    import torch
-    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
-    clip = clip_format(fmt, w, h)
-    frames = make_frames(clip, "noise", n, seed0=41)
-    frames[n // 2] = synth.frame(clip, "checker", seed=9)
-    parity = [(f * 3) & 1 for f in range(n)]
-    ora = Oracle(oracle_cfg(clip, **kw))
-    want = [ora.process(frames[f], parity=parity[f]) for f in range(n)]
-    dev = torch.device("cuda:0")
-    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
-    with SangNom2(clip, max_batch=n, **kw) as flt:
-        flt.set_bands(6, 0)
-        src = [torch.from_numpy(np.stack([frames[f][p] for f in range(n)]).view({1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes])).to(dev)
-               for p in range(clip.planes)]
-        dst = [torch.zeros((n,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
-        torch.cuda.synchronize()
-        flt.process_batch(src, dst, parity=parity)
-        flt.synchronize()
-        assert flt.info().banded_frames == n
-        for f in range(n):
-            for p in range(clip.planes):
-                got = dst[p][f].cpu().numpy().view(clip.dtype)
-                assert same(want[f][p], got), f"frame {f} plane {p}: " + describe_diff(want[f][p], got)
-    # the host ring: groups of one or two frames per launch
-    with SangNom2(clip, host_depth=4, **kw) as flt:
-        flt.set_bands(5, 0)
-        inflight, got = [], []
-        for f in range(n):
-            if len(inflight) == flt.host_slots():
-                got.append(flt.collect(inflight.pop(0)))
-            inflight.append(flt.submit(frames[f], parity[f]))
-        while inflight:
-            got.append(flt.collect(inflight.pop(0)))
-        assert flt.info().banded_frames == n
-        for f in range(n):
-            for p in range(clip.planes):
-                assert same(want[f][p], got[f][p]), f"ring frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
-
-
-@pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 512, 300, {}), ("YUV420P8", 256, 320, dict(aac=48)), ("Y16", 256, 240, {})])
-def test_filter_instances_on_their_own_threads(hip_lib, monkeypatch, fmt, w, h, kw):
-    """MT_MULTI_INSTANCE (SangNom2.h:63-66): the host runs several instances of the filter at once, each on its own thread
-    with its own context.  Four threads, each with a context of its own, call the synchronous entry point on their own
-    frames (the latency path: bands, checks, guarded pool kernels, each context on its own stream and scratch)."""
-    import threading
-    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
-    clip = clip_format(fmt, w, h)
-    T, N = 4, 6
-    frames = [[synth.frame(clip, "noise" if (t + f) % 3 else "checker", seed=100 * t + f) for f in range(N)] for t in range(T)]
-    want = []
-    for t in range(T):
-        ora = Oracle(oracle_cfg(clip, **kw))
-        want.append([ora.process(frames[t][f], parity=f & 1) for f in range(N)])
-    got = [[None] * N for _ in range(T)]
-    errors = []
-
-    def work(t):
-        try:
-            with SangNom2(clip, **kw) as flt:
-                for f in range(N):
-                    got[t][f] = flt.get_frame(frames[t][f], parity=f & 1)
-        except Exception as e:  # noqa: BLE001
-            errors.append((t, repr(e)))
-
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    assert not errors, errors
-    for t in range(T):
-        for f in range(N):
-            for p in range(len(want[t][f])):
-                assert same(want[t][f][p], got[t][f][p]), f"thread {t} frame {f} plane {p}"
-
-
-def test_launches_of_hundreds_of_small_frames_stay_on_the_whole_plane_sweeps(hip_lib, monkeypatch):
-    """More than 512 frames in one launch of an isolated-planes context (which has a scratch slot for each of them): the band
-    count works out as zero there -- once a division by it -- and the launch must take the whole-plane sweeps."""
-    import torch
-    monkeypatch.delenv("SN_PREFER_POOL", raising=False)
-    clip = clip_format("YUV420P8", 128, 80)
-    N = 600
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device=dev)
-    g.manual_seed(77)
-    src = [torch.randint(0, 256, (N, 80 >> (1 if p else 0), 128 >> (1 if p else 0)), device=dev, generator=g, dtype=torch.uint8) for p in range(3)]
-    outs = {}
-    for mode in ("auto", "fused"):
-        with SangNom2(clip, max_batch=N, mode=mode, isolated_planes=True, aac=48) as flt:
-            dst = [torch.zeros_like(s) for s in src]
-            torch.cuda.synchronize()
-            flt.process_batch(src, dst)
-            flt.synchronize()
-            info = flt.info()
-            assert (info.fused_frames, info.banded_frames) == (N, 0)
-            outs[mode] = [d.cpu().numpy() for d in dst]
-    for p in range(3):
-        assert np.array_equal(outs["auto"][p], outs["fused"][p])
-
-
-@pytest.mark.parametrize("fmt", ["YUV420P8", "YUV422P8", "YUV420P16", "YUV420PS"])
-@pytest.mark.parametrize("w,h", [(512, 400), (992, 720), (1472, 1000), (544, 400), (1024, 720)])
-def test_coupled_sweeps_equal_the_pool_path_where_the_cone_reaches_the_last_columns(hip_lib, fmt, w, h):
-    """Tall frames of widths whose last strip ends on lanes 62 / 63 (64 + 60 k lanes: 512, 992, 1472) and of their
-    neighbours: the hand-off's dependency cone then includes the last columns of the pool, which short test frames
-    never reach (the 8-bit sweeps once read zeros there).  Whole-plane sweeps against the pool path, byte for byte."""
-    hh = h if fmt != "YUV422P8" else h // 2
-    clip = clip_format(fmt, w, hh)
-    kw = dict(aa=128, aac=128)
-    for pattern in ("edges", "noise"):
-        src = synth.frame(clip, pattern, seed=5)
-        outs = {}
-        for mode in ("fused", "pool"):
-            with SangNom2(clip, mode=mode, **kw) as flt:
-                outs[mode] = flt.get_frame(src)
-        for p in range(3):
-            assert same(outs["pool"][p], outs["fused"][p]), f"{pattern} plane {p}: " + describe_diff(outs["pool"][p], outs["fused"][p])
-
-
-# ---- last in the file on purpose: hipHostRegister / hipHostUnregister on the test's own arrays.  With this test in the
-# middle of the suite, later tests that hand pageable numpy arrays to the synchronous entry point were hit, once in a
-# few runs, by a GPU page fault reported from the HSA runtime's event thread (three times in test_row_bands_match_oracle,
-# never when the band tests ran without this one before them); nothing in the library touches the arrays after
-# sn_unpin_host_buffer, which now also waits for the device first.
+# (round 2 kept this test last in the file because of a GPU page fault in later tests; DESIGN.md 7 has what became of it)
 @pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 512, 128, {}), ("YUV420P8", 256, 64, dict(aac=48)), ("Y16", 256, 64, dict(order=0)),
                                         ("YUV420P8", 256, 320, dict(aac=48, order=2)), ("YUV444P8", 128, 96, dict(aac=20, dh=True)),
                                         ("YUV422P8", 192, 64, dict(chroma=False, order=0)), ("YUV420P16", 128, 64, dict(luma=False, aac=30)),
@@ -1340,3 +1152,219 @@ def test_pinned_host_frames_skip_the_staging_copies(hip_lib, fmt, w, h, kw):
             unpin_host_array(dbuf)
     with pytest.raises(SangNomError):
         unpin_host_array(sbuf)
+
+
+@pytest.mark.parametrize("fmt,w,h,kw,bands,warm", BAND_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}-b{c[4]}" for c in BAND_CASES])
+@pytest.mark.parametrize("pattern", ["noise", "checker", "edges", "sine"])
+def test_row_bands_match_oracle(hip_lib, monkeypatch, fmt, w, h, kw, bands, warm, pattern):
+    """A frame cut into row bands equals the oracle whatever the content: where the run-up has not forgotten the
+    guessed state the check sends the frame to the pool path."""
+    from avisynth_sangnom2_amd import capi as _capi
+    monkeypatch.setitem(_capi.POLICY_DEFAULTS, "small_launches", _capi.SN_SMALL_AUTO)
+    clip = clip_format(fmt, w, h)
+    ora = Oracle(oracle_cfg(clip, **kw))
+    with SangNom2(clip, **kw) as flt:
+        flt.set_bands(bands, warm)
+        for f, src in enumerate(make_frames(clip, pattern, 3, seed0=11)):
+            want = ora.process(src, parity=f & 1)
+            got = flt.get_frame(src, parity=f & 1)
+            for p in range(len(want)):
+                assert same(want[p], got[p]), f"{pattern} frame {f} plane {p}: " + describe_diff(want[p], got[p])
+        info = flt.info()
+        if bands > 0:
+            assert info.banded_frames == 3
+        else:  # automatic: after a failed check the following launches skip the bands
+            assert 1 <= info.banded_frames <= 3 and (info.banded_frames == 3 or info.band_fallbacks > 0)
+        if pattern == "noise" and warm == 0:
+            assert info.band_fallbacks == 0  # the default run-up is long enough for noise
+
+
+@pytest.mark.parametrize("fmt,w,h", [("Y8", 512, 300), ("Y8", 3840, 2160), ("Y16", 512, 300), ("Y32", 512, 300)])
+def test_row_bands_that_fail_the_check_are_redone(hip_lib, monkeypatch, fmt, w, h):
+    """A run-up of one row leaves nearly every band with a wrong state: the check must notice and the pool path must
+    repair every such frame."""
+    from avisynth_sangnom2_amd import capi as _capi
+    monkeypatch.setitem(_capi.POLICY_DEFAULTS, "small_launches", _capi.SN_SMALL_AUTO)
+    clip = clip_format(fmt, w, h)
+    ora = Oracle(oracle_cfg(clip))
+    with SangNom2(clip) as flt:
+        flt.set_bands(16, 1)
+        for f, src in enumerate(make_frames(clip, "noise", 2, seed0=3)):
+            want = ora.process(src)
+            got = flt.get_frame(src)
+            assert same(want[0], got[0]), f"frame {f}: " + describe_diff(want[0], got[0])
+        info = flt.info()
+        assert info.banded_frames == 2 and info.band_fallbacks == 2
+        flt.set_bands(-1, 0)  # bands off: the same frames through the pool path / plain sweep
+        got = flt.get_frame(src)
+        assert same(want[0], got[0])
+        assert flt.info().banded_frames == 2
+
+
+def test_row_bands_pause_after_failed_checks(hip_lib, monkeypatch):
+    """Content on which the run-up does not forget the guessed state (a checkerboard) would pay for the bands and for the
+    pool path every time: after a failed check the next launches skip the bands."""
+    from avisynth_sangnom2_amd import capi as _capi
+    monkeypatch.setitem(_capi.POLICY_DEFAULTS, "small_launches", _capi.SN_SMALL_AUTO)
+    clip = clip_format("Y8", 512, 400)
+    ora = Oracle(oracle_cfg(clip))
+    src = synth.frame(clip, "checker", seed=2)
+    want = ora.process(src)
+    with SangNom2(clip) as flt:
+        banded = []
+        for f in range(12):
+            got = flt.get_frame(src)
+            assert same(want[0], got[0]), f"frame {f}"
+            banded.append(flt.info().banded_frames)
+        info = flt.info()
+        if info.band_fallbacks:  # the first frame failed its check: the next eight launches skip the bands, then one more try
+            assert banded[0] == banded[8] == 1 and info.banded_frames <= 2
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", [("YUV420P8", 512, 400, dict(aac=48)), ("YUV420P16", 256, 320, dict(aac=48, fresh_pool=True)),
+                                        ("YUV422PS", 256, 256, dict(aac=48))])
+def test_row_bands_serve_isolated_planes(hip_lib, monkeypatch, fmt, w, h, kw):
+    """isolated_planes: every plane is a plane on its own, so single frames are cut into row bands too (4:2:0 included);
+    same bytes as the whole-plane sweeps."""
+    from avisynth_sangnom2_amd import capi as _capi
+    monkeypatch.setitem(_capi.POLICY_DEFAULTS, "small_launches", _capi.SN_SMALL_AUTO)
+    clip = clip_format(fmt, w, h)
+    frames = make_frames(clip, "noise", 3, seed0=17)
+    with SangNom2(clip, isolated_planes=True, **kw) as flt:
+        got = [flt.get_frame(src, parity=f & 1) for f, src in enumerate(frames)]
+        info = flt.info()
+        assert (info.banded_frames, info.band_fallbacks) == (3, 0)
+    with SangNom2(clip, isolated_planes=True, mode="fused", **kw) as flt:
+        want = [flt.get_frame(src, parity=f & 1) for f, src in enumerate(frames)]
+        assert flt.info().banded_frames == 0
+    for f in range(3):
+        for p in range(3):
+            assert same(want[f][p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
+
+
+@pytest.mark.parametrize("fmt,w,h,kw,n", [("Y8", 512, 300, {}, 5), ("Y8", 64, 200, dict(order=0), 7), ("Y16", 1056, 240, dict(aa=20), 3),
+                                          ("YUV444PS", 256, 200, dict(aac=48), 4), ("YUV420P8", 512, 320, dict(aac=48), 6)])
+def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, h, kw, n):
+    """A launch of a few frames (a host ring group, a short device batch) is cut into bands as well: frames x bands
+    workgroups, one flag per frame.  One of the frames is a checkerboard, which may fail its check on its own."""
+    import torch
+    from avisynth_sangnom2_amd import capi as _capi
+    monkeypatch.setitem(_capi.POLICY_DEFAULTS, "small_launches", _capi.SN_SMALL_AUTO)
+    clip = clip_format(fmt, w, h)
+    frames = make_frames(clip, "noise", n, seed0=41)
+    frames[n // 2] = synth.frame(clip, "checker", seed=9)
+    parity = [(f * 3) & 1 for f in range(n)]
+    ora = Oracle(oracle_cfg(clip, **kw))
+    want = [ora.process(frames[f], parity=parity[f]) for f in range(n)]
+    dev = torch.device("cuda:0")
+    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
+    with SangNom2(clip, max_batch=n, **kw) as flt:
+        flt.set_bands(6, 0)
+        src = [torch.from_numpy(np.stack([frames[f][p] for f in range(n)]).view({1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes])).to(dev)
+               for p in range(clip.planes)]
+        dst = [torch.zeros((n,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
+        torch.cuda.synchronize()
+        flt.process_batch(src, dst, parity=parity)
+        flt.synchronize()
+        assert flt.info().banded_frames == n
+        for f in range(n):
+            for p in range(clip.planes):
+                got = dst[p][f].cpu().numpy().view(clip.dtype)
+                assert same(want[f][p], got), f"frame {f} plane {p}: " + describe_diff(want[f][p], got)
+    # the host ring: groups of one or two frames per launch
+    with SangNom2(clip, host_depth=4, **kw) as flt:
+        flt.set_bands(5, 0)
+        inflight, got = [], []
+        for f in range(n):
+            if len(inflight) == flt.host_slots():
+                got.append(flt.collect(inflight.pop(0)))
+            inflight.append(flt.submit(frames[f], parity[f]))
+        while inflight:
+            got.append(flt.collect(inflight.pop(0)))
+        assert flt.info().banded_frames == n
+        for f in range(n):
+            for p in range(clip.planes):
+                assert same(want[f][p], got[f][p]), f"ring frame {f} plane {p}: " + describe_diff(want[f][p], got[f][p])
+
+
+@pytest.mark.parametrize("fmt,w,h,kw", [("Y8", 512, 300, {}), ("YUV420P8", 256, 320, dict(aac=48)), ("Y16", 256, 240, {})])
+def test_filter_instances_on_their_own_threads(hip_lib, monkeypatch, fmt, w, h, kw):
+    """MT_MULTI_INSTANCE (SangNom2.h:63-66): the host runs several instances of the filter at once, each on its own thread
+    with its own context.  Four threads, each with a context of its own, call the synchronous entry point on their own
+    frames (the latency path: bands, checks, guarded pool kernels, each context on its own stream and scratch)."""
+    import threading
+    from avisynth_sangnom2_amd import capi as _capi
+    monkeypatch.setitem(_capi.POLICY_DEFAULTS, "small_launches", _capi.SN_SMALL_AUTO)
+    clip = clip_format(fmt, w, h)
+    T, N = 4, 6
+    frames = [[synth.frame(clip, "noise" if (t + f) % 3 else "checker", seed=100 * t + f) for f in range(N)] for t in range(T)]
+    want = []
+    for t in range(T):
+        ora = Oracle(oracle_cfg(clip, **kw))
+        want.append([ora.process(frames[t][f], parity=f & 1) for f in range(N)])
+    got = [[None] * N for _ in range(T)]
+    errors = []
+
+    def work(t):
+        try:
+            with SangNom2(clip, **kw) as flt:
+                for f in range(N):
+                    got[t][f] = flt.get_frame(frames[t][f], parity=f & 1)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for t in range(T):
+        for f in range(N):
+            for p in range(len(want[t][f])):
+                assert same(want[t][f][p], got[t][f][p]), f"thread {t} frame {f} plane {p}"
+
+
+def test_launches_of_hundreds_of_small_frames_stay_on_the_whole_plane_sweeps(hip_lib, monkeypatch):
+    """More than 512 frames in one launch of an isolated-planes context (which has a scratch slot for each of them): the band
+    count works out as zero there -- once a division by it -- and the launch must take the whole-plane sweeps."""
+    import torch
+    from avisynth_sangnom2_amd import capi as _capi
+    monkeypatch.setitem(_capi.POLICY_DEFAULTS, "small_launches", _capi.SN_SMALL_AUTO)
+    clip = clip_format("YUV420P8", 128, 80)
+    N = 600
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    src = [torch.randint(0, 256, (N, 80 >> (1 if p else 0), 128 >> (1 if p else 0)), device=dev, generator=g, dtype=torch.uint8) for p in range(3)]
+    outs = {}
+    for mode in ("auto", "fused"):
+        with SangNom2(clip, max_batch=N, mode=mode, isolated_planes=True, aac=48) as flt:
+            dst = [torch.zeros_like(s) for s in src]
+            torch.cuda.synchronize()
+            flt.process_batch(src, dst)
+            flt.synchronize()
+            info = flt.info()
+            assert (info.fused_frames, info.banded_frames) == (N, 0)
+            outs[mode] = [d.cpu().numpy() for d in dst]
+    for p in range(3):
+        assert np.array_equal(outs["auto"][p], outs["fused"][p])
+
+
+@pytest.mark.parametrize("fmt", ["YUV420P8", "YUV422P8", "YUV420P16", "YUV420PS"])
+@pytest.mark.parametrize("w,h", [(512, 400), (992, 720), (1472, 1000), (544, 400), (1024, 720)])
+def test_coupled_sweeps_equal_the_pool_path_where_the_cone_reaches_the_last_columns(hip_lib, fmt, w, h):
+    """Tall frames of widths whose last strip ends on lanes 62 / 63 (64 + 60 k lanes: 512, 992, 1472) and of their
+    neighbours: the hand-off's dependency cone then includes the last columns of the pool, which short test frames
+    never reach (the 8-bit sweeps once read zeros there).  Whole-plane sweeps against the pool path, byte for byte."""
+    hh = h if fmt != "YUV422P8" else h // 2
+    clip = clip_format(fmt, w, hh)
+    kw = dict(aa=128, aac=128)
+    for pattern in ("edges", "noise"):
+        src = synth.frame(clip, pattern, seed=5)
+        outs = {}
+        for mode in ("fused", "pool"):
+            with SangNom2(clip, mode=mode, **kw) as flt:
+                outs[mode] = flt.get_frame(src)
+        for p in range(3):
+            assert same(outs["pool"][p], outs["fused"][p]), f"{pattern} plane {p}: " + describe_diff(outs["pool"][p], outs["fused"][p])

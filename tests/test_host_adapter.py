@@ -33,7 +33,7 @@ def _run(tmp_path, clip, kw, frames, parities, extra=()):
             f.write(struct.pack("<i", par))
             for pl in fr:
                 f.write(np.ascontiguousarray(pl).tobytes())
-    env = dict(os.environ, SN_PREFER_POOL="0")  # small clips: reach the fused sweeps, not auto mode's pool path
+    env = dict(os.environ, SN_HOST_TEST_SWEEPS="1")  # small clips: reach the fused sweeps, not auto mode's small-launch paths
     r = subprocess.run([BIN, fin, fout, *[str(x) for x in extra]], capture_output=True, text=True, timeout=300, env=env)
     return r, fout
 

@@ -79,16 +79,16 @@ def main():
                     o = mk() if ext == "fresh" else per_plane.setdefault(p, mk())
                     outs.append(o.process([pl], parity=parity[f])[0])
                 want.append(outs)
-        os.environ["SN_PREFER_POOL"] = rng.choice(["0", "1"])  # the whole-plane sweeps, or auto mode's small-launch paths (bands, pool kernels)
+        small = rng.choice([1, 0])  # SN_SMALL_SWEEP: the whole-plane sweeps, or auto mode's small-launch paths (bands, pool kernels)
         try:
-            flt = SangNom2(clip, host_depth=rng.choice([1, 2, 3, 4, 5, 8, 12]), max_batch=nframes, isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", **kw)
+            flt = SangNom2(clip, host_depth=rng.choice([1, 2, 3, 4, 5, 8, 12]), max_batch=nframes, isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", small_launches=small, **kw)
         except Exception as e:  # a geometry the library rejects must be one it documents
             if "exceeds the supported maximum" in str(e):
                 continue
             raise
         with flt:
             band_set = None
-            if os.environ["SN_PREFER_POOL"] == "1":  # auto mode: the row bands too, now and then with a run-up that is too short
+            if small == 0:  # auto mode: the row bands too, now and then with a run-up that is too short
                 band_set = (rng.choice([0, 0, 2, 3, 5, 9, 16]), rng.choice([0, 0, 0, 1, 6, 12]))
                 flt.set_bands(*band_set)
             got = []
@@ -131,7 +131,7 @@ def main():
                     np.savez(f"gpurun_out/fuzz_mismatch_{n}.npz", **{f"src{q}": frames[f][q] for q in range(clip.planes)},
                              **{f"want{q}": want[f][q] for q in range(clip.planes)}, **{f"got{q}": got[f][q] for q in range(clip.planes)})
                     print(f"MISMATCH {fmt} {w}x{h} {kw} ext={ext} way={way} frame {f}/{nframes} plane {p} pattern={pattern} parity={parity} "
-                          f"prefer_pool={os.environ['SN_PREFER_POOL']} bands={band_set} banded={info.banded_frames} fallbacks={info.band_fallbacks} "
+                          f"small_launches={small} bands={band_set} banded={info.banded_frames} fallbacks={info.band_fallbacks} "
                           f"fused={info.fused_frames} n={len(d)} rows {d[:, 0].min()}..{d[:, 0].max()} cols {d[:, 1].min()}..{d[:, 1].max()}", flush=True)
         n += 1
         if n % 50 == 0:

@@ -52,8 +52,7 @@ def main():
                 src.append(torch.randint(0, 1 << clip.bits, (n, hp, wp), device=dev, generator=g, dtype=torch.int32).to(torch.int16))
             else:
                 src.append(torch.randint(0, 256, (n, hp, wp), device=dev, generator=g, dtype=torch.uint8))
-        os.environ["SN_PREFER_POOL"] = "0"  # this is about the sweeps: never hand a small launch to the pool path
-        flt = SangNom2(clip, max_batch=n, **kw)
+        flt = SangNom2(clip, max_batch=n, small_launches=1, **kw)  # SN_SMALL_SWEEP: this is about the sweeps, never hand a small launch to the pool path
         assert flt.info().fused_eligible == 1, fmt
         ref = [torch.empty_like(s) for s in src]
         with SangNom2(clip, max_batch=n, mode="pool", **kw) as pool:
