@@ -1302,6 +1302,10 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     }
     if (piped) SN_HIP(c, hipStreamSynchronize(g.out));
     SN_HIP(c, hipStreamSynchronize(c->stream));
+    // The copies on g.in are complete by now (the kernels waited for them), but the RUNTIME has to hear of it as well: a
+    // stream that is never synchronised keeps its commands -- and with them the runtime's transient registration of the
+    // caller's pageable planes -- alive after the call has returned and the caller has freed or recycled that memory.
+    if (piped) SN_HIP(c, hipStreamSynchronize(g.in));
     return SN_OK;
 }
 
