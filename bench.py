@@ -62,7 +62,7 @@ def algorithmic_bytes_per_frame(clip, flt, kw) -> int:
     return total
 
 
-PROFILE_TAG = "r2"  # profiles/<tag>_counters.json is what recorded_counters() reads
+PROFILE_TAG = "r3"  # profiles/<tag>_counters.json is what recorded_counters() reads
 
 
 def recorded_counters(workload: str, batch: int):
