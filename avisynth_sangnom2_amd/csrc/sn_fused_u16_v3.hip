@@ -35,9 +35,33 @@ struct Line {
     __device__ __forceinline__ unsigned B(int j) const { return FB[j] >> 16; }
 };
 
+// The same with F and B in registers of their own (no extraction per use): for the sweeps whose stage 3 gathers its two
+// taps from LDS (planes on their own) -- there a line in this form only serves stage 1 and the kernel has the registers.
+struct WideLine {
+    unsigned P[PXL + 6];
+    unsigned Fv[PXL], Bv[PXL];
+    __device__ __forceinline__ unsigned F(int j) const { return Fv[j]; }
+    __device__ __forceinline__ unsigned B(int j) const { return Bv[j]; }
+};
+
 struct Raw {  // bytes [2(x0-4), 2(x0+12)): pixels x0-4 .. x0+11 as 8 dwords
     u32x4 a, b;
 };
+
+// ---- Stage 3 as a gather (planes on their own) ------------------------------------------------------------------------
+// The ladder's winner picks ONE sample of the line above and ONE of the line below (SangNom2.cpp:214-249: c(k) and n(-k),
+// or the two SangNom values); the result is their rounded average.  The 8-bit sweep does that with byte permutes over
+// registers; a 16-bit pixel pair's candidates are 16 bytes, more than v_perm_b32 sees, so here every lane READS its two
+// taps from LDS with a computed address.  A line is kept in LDS as 32 halfwords per thread -- 0..15 the pixels x0-4 ..
+// x0+11 exactly as loaded (edge-clamped), 16..23 the forward, 24..31 the backward SangNom values -- for the two rows that
+// use it (a ring of three lines, each thread reads what it wrote; 17 dwords per thread so that the lanes spread over the
+// banks).  The winner's rank code (P4 / threshold 0, P5 1, P3 2, P6 3, P2 4, P7 5, P1 6, P8 7, P0 12) goes through two
+// byte tables (v_perm_b32; selector 12 reads 0x00, the tables are stored XOR 1 / XOR 7 so that 0x00 means P0's tap):
+// halfword index of pixel j's upper tap = j + (4 + k | 16 | 24), of its lower tap = j + (4 - k | 24 | 16).
+// 6 instructions and two ds_read_u16 per pixel where the select tree took 31 instructions.
+constexpr int kGatherDwords = 17;  // per thread and line
+constexpr unsigned kLutCLo = 0x04111905u, kLutCHi = 0x06030702u;  // code -> (4 + k, c -> B 24, c -> F 16) ^ 1
+constexpr unsigned kLutNLo = 0x041f1703u, kLutNHi = 0x06010502u;  // code -> (4 - k, n -> F 16, n -> B 24) ^ 7
 
 struct LaneRole {
     bool edge_wave;  // wave holds the first or last column of the sweep or of the source lines
@@ -49,7 +73,12 @@ struct LaneRole {
     unsigned key_mask;               // 0xffff0 in a VGPR (operand of the and-or that forms the ladder keys)
 };
 
-__device__ __forceinline__ void unpack(Line& L, const Raw& q, const LaneRole& role)
+struct GatherLine {  // what park_gather() writes: 8 dwords of pixels, 4 of F pairs, 4 of B pairs
+    unsigned d[8], f[4], b[4];
+};
+
+template <class LineT>
+__device__ __forceinline__ void unpack(LineT& L, const Raw& q, const LaneRole& role, GatherLine* G = nullptr)
 {
     // dword i of (a, b) holds pixels x0 - 4 + 2i (low half) and x0 - 3 + 2i; the lane that owns column 0
     // loaded from column 0 instead, so its dwords are two slots early
@@ -58,6 +87,10 @@ __device__ __forceinline__ void unpack(Line& L, const Raw& q, const LaneRole& ro
 #pragma unroll
         for (int i = 7; i >= 2; --i) d[i] = d[i - 2];
     }
+    if (role.edge_wave) {  // loadPixel's clamp, SangNom2.cpp:25-34, on the dwords (the gather reads them as they are)
+        if (role.first) d[0] = d[1] = (d[2] & kVal) * 0x10001u;        // pixels x0-4 .. x0-1 := pixel x0
+        if (role.line_last) d[6] = d[7] = (d[5] >> 16) * 0x10001u;     // pixels x0+8 .. x0+11 := pixel x0+7
+    }
     L.P[0] = d[0] >> 16;
 #pragma unroll
     for (int i = 1; i < 7; ++i) {
@@ -65,24 +98,35 @@ __device__ __forceinline__ void unpack(Line& L, const Raw& q, const LaneRole& ro
         L.P[2 * i] = d[i] >> 16;
     }
     L.P[13] = d[7] & kVal;
-    if (role.edge_wave) {  // loadPixel's clamp, SangNom2.cpp:25-34
-        if (role.first) L.P[0] = L.P[1] = L.P[2] = L.P[3];
-        if (role.line_last) L.P[11] = L.P[12] = L.P[13] = L.P[10];
-    }
     // F = ((4a + 5b - c) >> 3) mod 65536, B likewise mirrored; a bias of 8 * 65536 keeps the sum positive
     // and drops out of the result
+    unsigned fv[PXL], bv[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
         const unsigned a = L.P[j + 2], b = L.P[j + 3], c = L.P[j + 4];
         const unsigned x5 = 4 * b + b + 0x80000u;
-        const unsigned f = ((4 * a + x5 - c) >> 3) & kVal;
-        const unsigned bb = ((4 * c + x5 - a) >> 3) & kVal;
-        L.FB[j] = f | (bb << 16);
+        fv[j] = ((4 * a + x5 - c) >> 3) & kVal;
+        bv[j] = ((4 * c + x5 - a) >> 3) & kVal;
+        if constexpr (std::is_same<LineT, WideLine>::value) {
+            L.Fv[j] = fv[j];
+            L.Bv[j] = bv[j];
+        } else {
+            L.FB[j] = fv[j] | (bv[j] << 16);
+        }
+    }
+    if (G) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) G->d[i] = d[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            G->f[i] = fv[2 * i] | (fv[2 * i + 1] << 16);
+            G->b[i] = bv[2 * i] | (bv[2 * i + 1] << 16);
+        }
     }
 }
 
-template <int BUF>
-__device__ __forceinline__ unsigned cost(const Line& c, const Line& n, int j)
+template <int BUF, class LineT>
+__device__ __forceinline__ unsigned cost(const LineT& c, const LineT& n, int j)
 {
     const int i = j + 3;
     if constexpr (BUF == 0) return absdiff(c.P[i - 3], n.P[i + 3]);
@@ -98,8 +142,8 @@ __device__ __forceinline__ unsigned cost(const Line& c, const Line& n, int j)
 
 // acc + cost<BUF>: v_sad_u16 adds its third operand, so S = A + D and A' = O + D are ONE instruction each and D itself
 // never exists (with two waves per SIMD an instruction costs the same whatever it does: fewer is faster)
-template <int BUF>
-__device__ __forceinline__ unsigned cost_acc(const Line& c, const Line& n, int j, unsigned acc)
+template <int BUF, class LineT>
+__device__ __forceinline__ unsigned cost_acc(const LineT& c, const LineT& n, int j, unsigned acc)
 {
     const int i = j + 3;
     if constexpr (BUF == 0) return __builtin_amdgcn_sad_u16(c.P[i - 3], n.P[i + 3], acc);
@@ -128,11 +172,26 @@ __device__ __forceinline__ unsigned tap_sum(const Line& c, const Line& n, int j)
     return c.P[i + 3] + n.P[i - 3];
 }
 
-template <int BUF>
-constexpr unsigned rank_of()  // P4, P5, P3, P6, P2, P7, P1, P8, P0 -> 1..9 (SangNom2.cpp:214-249)
+#ifndef SN_U16_GATHER_ALL
+#define SN_U16_GATHER_ALL 1
+#endif
+#ifndef SN_U16_POOL_RB
+#define SN_U16_POOL_RB 9
+#endif
+#ifndef SN_U16_POOL_WIDE
+#define SN_U16_POOL_WIDE 0
+#endif
+__host__ __device__ constexpr bool gather_stage3(int mode) { return SN_U16_GATHER_ALL || !has_pools(mode); }
+__host__ __device__ constexpr bool wide_lines(int mode) { return !has_pools(mode) || SN_U16_POOL_WIDE; }
+template <int MODE>
+using LineOf = typename std::conditional<wide_lines(MODE), WideLine, Line>::type;
+
+template <int BUF, int MODE>
+constexpr unsigned rank_of()  // P4, P5, P3, P6, P2, P7, P1, P8, P0 -> 1..9 (SangNom2.cpp:214-249), or the gather's codes
 {
     constexpr unsigned r[9] = {9, 7, 5, 3, 1, 2, 4, 6, 8};
-    return r[BUF];
+    constexpr unsigned code[9] = {12, 6, 4, 2, 0, 1, 3, 5, 7};
+    return gather_stage3(MODE) ? code[BUF] : r[BUF];
 }
 
 // The box of a plane on its own: two variants, the edge waves branch (measured: the uniform box below is 0.7 % slower
@@ -212,10 +271,11 @@ struct RowCtx {
     int vin;  // kChroma: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
     int vout;
     bool any_out;  // wave-uniform: some lane of this wave stores in this row
+    int slot_c, slot_n;  // gather modes: LDS slots of the lines above / below the interpolated one
 };
 
 template <int BUF, int MODE, bool S1>
-__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const Line& n, const Line& nn,
+__device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const LineOf<MODE>& n, const LineOf<MODE>& nn,
                                             const LaneRole& role, const PoolIO& io, const RowCtx& rc, const u32x4& stale)
 {
     unsigned D[PXL], S[PXL], Bx[PXL], O[PXL];
@@ -230,7 +290,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
         }
 #pragma unroll
         for (int j = 0; j < PXL; ++j) {
-            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF>());  // (sum / 16 mod 65536) << 4 | rank
+            const unsigned key = and_or(Bx[j], role.key_mask, rank_of<BUF, MODE>());  // (sum / 16 mod 65536) << 4 | rank
             O[j] = key >> 4;                                                     // SangNom2.cpp:152
             A[j] = S1 ? cost_acc<BUF>(n, nn, j, O[j]) : O[j];
             kmin[j] = umin(kmin[j], key);
@@ -262,7 +322,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
         const unsigned t = Bx[j] & 0xffff0u;  // O << 4; shared by O and the key: three full-rate ops
         O[j] = t >> 4;                        // (sum / 16) wraps to uint16_t, SangNom2.cpp:152
         A[j] = O[j] + D[j];
-        kmin[j] = umin(kmin[j], t | rank_of<BUF>());
+        kmin[j] = umin(kmin[j], t | rank_of<BUF, MODE>());
     }
     if constexpr (MODE == kChroma) io.store(BUF, rc.r, rc.vout, O);  // (kChromaLast hands nothing on)
 }
@@ -286,11 +346,28 @@ __device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], const u32x
     if (vout_any) io.store(BUF, r, vout, O);
 }
 
-__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? 4 : 9; }
+__host__ __device__ constexpr int reg_buffers(int mode) { return has_pools(mode) ? (gather_stage3(mode) ? SN_U16_POOL_RB : 4) : 9; }
 
 template <int NT, int RB>
 struct Parked {
-    uint4* v;  // [6][NT]: the parked line
+    uint4* v;  // [6][NT]: the parked line; gather modes: [3 lines][NT][kGatherDwords] dwords (see GatherLine)
+    __device__ __forceinline__ void park_gather(int tid, int slot, const GatherLine& G) const
+    {
+        unsigned* to = reinterpret_cast<unsigned*>(v) + (slot * NT + tid) * kGatherDwords;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) to[i] = G.d[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            to[8 + i] = G.f[i];
+            to[12 + i] = G.b[i];
+        }
+    }
+    // byte address (in the workgroup's LDS window) of halfword 0 of this thread's record of line `slot`
+    __device__ __forceinline__ const unsigned short* gather_base(int tid, int slot) const
+    {
+        return reinterpret_cast<const unsigned short*>(reinterpret_cast<const unsigned*>(v) + (slot * NT + tid) * kGatherDwords);
+    }
+    __device__ __forceinline__ void park(int, const WideLine&) const {}  // never called: gather modes park a GatherLine
     uint4* a;  // [9 - RB][2][NT]: A of the LDS-resident buffers
     __device__ __forceinline__ void load_A(int tid, int b, unsigned (&A)[PXL]) const
     {
@@ -331,7 +408,7 @@ struct Out {
 
 template <int MODE, bool S1, bool S3, int NT>
 __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk,
-                                        int tid, const Line& n, const Line& nn, const LaneRole& role, unsigned thr_key,
+                                        int tid, const LineOf<MODE>& n, const LineOf<MODE>& nn, const LaneRole& role, unsigned thr_key,
                                         const PoolIO& io, const RowCtx& rc)
 {
     unsigned kmin[PXL];
@@ -366,6 +443,32 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 
     Out o{};
     if constexpr (!S3) return o;
+    if constexpr (gather_stage3(MODE)) {
+        const unsigned short* cbase = pk.gather_base(tid, rc.slot_c);
+        const unsigned short* nbase = pk.gather_base(tid, rc.slot_n);
+        unsigned v[PXL];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            // the four winners' codes as bytes, then their taps' halfword offsets relative to the pixel
+            const unsigned k01 = __builtin_amdgcn_perm(kmin[4 * g + 1], kmin[4 * g + 0], 0x0c0c0400u);
+            const unsigned codes = __builtin_amdgcn_perm(kmin[4 * g + 3], kmin[4 * g + 2], 0x04000c0cu) | k01;
+            const unsigned c4 = codes & 0x0f0f0f0fu;
+            const unsigned tc = __builtin_amdgcn_perm(kLutCHi, kLutCLo, c4) ^ 0x01010101u;
+            const unsigned tn = __builtin_amdgcn_perm(kLutNHi, kLutNLo, c4) ^ 0x07070707u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = 4 * g + i;
+                const unsigned oc = (tc >> (8 * i)) & 0xffu, on = (tn >> (8 * i)) & 0xffu;
+                const unsigned ctap = cbase[oc + j], ntap = nbase[on + j];
+                v[j] = (ctap + ntap + 1u) >> 1;  // (a + b + 1) >> 1, SangNom2.cpp:48-52
+            }
+        }
+        o.v.x = v[0] | (v[1] << 16);
+        o.v.y = v[2] | (v[3] << 16);
+        o.v.z = v[4] | (v[5] << 16);
+        o.v.w = v[6] | (v[7] << 16);
+        return o;
+    } else {
     Line c;
     pk.unpark(tid, c);
     unsigned v[PXL];
@@ -393,6 +496,7 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
     o.v.z = v[4] | (v[5] << 16);
     o.v.w = v[6] | (v[7] << 16);
     return o;
+    }
 }
 
 // LDS mailbox: [refresh parity][wave][side][slot][72 A registers]; ghost lane `slot` on `side` of wave W
@@ -408,7 +512,8 @@ struct Mailbox {
 
 __host__ __device__ constexpr int lds_bytes(int nw, int mode)
 {
-    return (6 + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64 + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
+    return ((gather_stage3(mode) ? (3 * kGatherDwords * 4 + 15) / 16 : 6) + (kBuffers - reg_buffers(mode)) * 2) * 16 * nw * 64
+           + 2 * (nw + 1) * 2 * GH * kBuffers * PXL * 4;
 }
 
 template <int NW, int MODE, bool BAND>
@@ -425,7 +530,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     const int tid = (int)threadIdx.x - sub * (NW * 64);
     Parked<NT, RB> parked;
     parked.v = reinterpret_cast<uint4*>(lds_raw + sub * lds_bytes(NW, MODE));
-    parked.a = parked.v + 6 * NT;
+    parked.a = parked.v + (gather_stage3(MODE) ? (3 * kGatherDwords * 4 + 15) / 16 : 6) * NT;
     Mailbox<NW> mb;
     mb.h = reinterpret_cast<unsigned*>(parked.a + (kBuffers - RB) * 2 * NT);
     const int wave = tid >> 6;
@@ -595,15 +700,23 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     }
 
     // a band copies the kept lines ra .. rb (the top band line 0 as well)
-    Line L0, L1;
+    LineOf<MODE> L0, L1;
     Raw q0 = load_raw(src_line + (r0 - 1) * src_step);
     Raw q1 = nk > 1 ? load_raw(src_line + r0 * src_step) : q0;
     keep(dst_line, q0, top);
     if (a.offset == 1) keep(0, q0, top);  // the line that cannot be interpolated, SangNom2.cpp:386-391
     if (nk > 1) keep(dst_line + r0 * dst_step, q1, r0 == ra);
-    unpack(L0, q0, role);
-    unpack(L1, q1, role);
-    parked.park(tid, L0);
+    if constexpr (gather_stage3(MODE)) {
+        GatherLine G;
+        unpack(L0, q0, role, &G);
+        parked.park_gather(tid, (r0 - 1) % 3, G);  // K[r0 - 1]: the upper line of row r0
+        unpack(L1, q1, role, &G);
+        parked.park_gather(tid, r0 % 3, G);        // K[r0]: its lower line
+    } else {
+        unpack(L0, q0, role);
+        unpack(L1, q1, role);
+        parked.park(tid, L0);
+    }
 
     const bool first_in = chroma_mode(MODE) && a.rows_in >= 1 && in_cone(1, a.cone_in);
 
@@ -654,13 +767,19 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     Out pending{};
     TurnTaking turns;
     turns.init(a.turn_shift);
-    auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
+    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag) __attribute__((always_inline)) {
         constexpr bool S1 = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
         turns.update();
         Raw qnext = qn;
         if constexpr (S1) {
-            unpack(nn, qn, role);  // waits for the line prefetched one row ago
+            if constexpr (gather_stage3(MODE)) {
+                GatherLine G;
+                unpack(nn, qn, role, &G);  // waits for the line prefetched one row ago
+                parked.park_gather(tid, (r + 1) % 3, G);  // K[r + 1]: lower line of the next row, upper line of the one after
+            } else {
+                unpack(nn, qn, role);
+            }
             keep(dst_keep, qn, !BAND || (r + 1 >= ra && r < rb));
             dst_keep += dst_step;
         }
@@ -695,12 +814,14 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         rc.vin = rc.vout = kOutOfRange;
         if constexpr (chroma_mode(MODE)) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
         rc.any_out = false;
+        rc.slot_c = (r - 1) % 3;
+        rc.slot_n = r % 3;
         if constexpr (has_pools(MODE)) {
             rc.vout = (r <= a.rows_out && (!BAND || r >= ra) && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
         }
         pending = row_step<MODE, S1, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
-        if constexpr (S1) parked.park(tid, n);  // n is the next row's c
+        if constexpr (S1 && !gather_stage3(MODE)) parked.park(tid, n);  // n is the next row's c
         if (r < sweep && r % K == 0) {
             const int wpar = ((r + 1) / K) & 1;
             if (pub_right || pub_left) {
@@ -754,7 +875,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         else leave_state(1);
         put(out_row, pending);
     } else {
-        for (int r = 1; r < nr; ++r) {
+        // two rows per trip with the roles of the two line registers swapped: no copy of a line per row
+        int r = 1;
+        for (; r + 1 < nr; r += 2) {
+            step(r, L1, L0, T{}, T{});
+            step(r + 1, L0, L1, T{}, T{});
+        }
+        if (r < nr) {
             step(r, L1, L0, T{}, T{});
             L1 = L0;
         }
