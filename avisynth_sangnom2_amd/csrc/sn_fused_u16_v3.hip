@@ -274,7 +274,9 @@ struct RowCtx {
     int slot_c, slot_n;  // gather modes: LDS slots of the lines above / below the interpolated one
 };
 
-template <int BUF, int MODE, bool S1>
+// STORE: the luma sweep's smoothed row goes to pool_out (rows past the hand-off run a loop without the packing: no
+// branch inside a buffer step, see sn_fused_u8_v3.hip)
+template <int BUF, int MODE, bool S1, bool STORE>
 __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const LineOf<MODE>& n, const LineOf<MODE>& nn,
                                             const LaneRole& role, const PoolIO& io, const RowCtx& rc, const u32x4& stale)
 {
@@ -295,9 +297,7 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             A[j] = S1 ? cost_acc<BUF>(n, nn, j, O[j]) : O[j];
             kmin[j] = umin(kmin[j], key);
         }
-        if constexpr (has_pools(MODE)) {
-            if (rc.any_out) io.store(BUF, rc.r, rc.vout, O);  // the luma sweep packs its hand-off only where a lane stores
-        }
+        if constexpr (has_pools(MODE) && STORE) io.store(BUF, rc.r, rc.vout, O);  // lanes that keep nothing: out-of-range voffset
         return;
     }
     if constexpr (chroma_mode(MODE)) {
@@ -406,7 +406,7 @@ struct Out {
     u32x4 v;  // 8 interpolated 16-bit pixels
 };
 
-template <int MODE, bool S1, bool S3, int NT>
+template <int MODE, bool S1, bool S3, bool STORE, int NT>
 __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk,
                                         int tid, const LineOf<MODE>& n, const LineOf<MODE>& nn, const LaneRole& role, unsigned thr_key,
                                         const PoolIO& io, const RowCtx& rc)
@@ -422,11 +422,11 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
             if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.vin);
         }
         if constexpr (B < reg_buffers(MODE)) {
-            buffer_step<B, MODE, S1>(A[B], kmin, n, nn, role, io, rc, st0);
+            buffer_step<B, MODE, S1, STORE>(A[B], kmin, n, nn, role, io, rc, st0);
         } else {
             unsigned t[PXL];
             pk.load_A(tid, B, t);
-            buffer_step<B, MODE, S1>(t, kmin, n, nn, role, io, rc, st0);
+            buffer_step<B, MODE, S1, STORE>(t, kmin, n, nn, role, io, rc, st0);
             pk.store_A(tid, B, t);
         }
         if constexpr (chroma_mode(MODE)) st0 = st1;
@@ -767,9 +767,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     Out pending{};
     TurnTaking turns;
     turns.init(a.turn_shift);
-    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag) __attribute__((always_inline)) {
+    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag, auto store_tag) __attribute__((always_inline)) {
         constexpr bool S1 = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
+        constexpr bool STORE = decltype(store_tag)::value;
         turns.update();
         Raw qnext = qn;
         if constexpr (S1) {
@@ -820,7 +821,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
             rc.vout = (r <= a.rows_out && (!BAND || r >= ra) && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
         }
-        pending = row_step<MODE, S1, S3>(A, parked, tid, n, nn, role, thr_key, io, rc);
+        pending = row_step<MODE, S1, S3, STORE>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S1 && !gather_stage3(MODE)) parked.park(tid, n);  // n is the next row's c
         if (r < sweep && r % K == 0) {
             const int wpar = ((r + 1) / K) & 1;
@@ -860,37 +861,53 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
                 for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * NT] = real ? t[j] : 0u;
             }
         };
+        using ST = std::integral_constant<bool, MODE == kLumaSpill>;
         int r = r0;
-        for (; r < ra; ++r) {  // the run-up: nothing interpolated
-            step(r, L1, L0, T{}, F{});
+        for (; r < ra; ++r) {  // the run-up: nothing interpolated, nothing handed on
+            step(r, L1, L0, T{}, F{}, F{});
             L1 = L0;
         }
         leave_state(0);
         const int own_next = rb < nr ? rb + 1 : nr;
         for (; r < own_next; ++r) {
-            step(r, L1, L0, T{}, T{});
+            step(r, L1, L0, T{}, T{}, ST{});
             L1 = L0;
         }
-        if (rb == nr) step(nr, L1, L0, F{}, T{});
+        if (rb == nr) step(nr, L1, L0, F{}, T{}, ST{});
         else leave_state(1);
         put(out_row, pending);
     } else {
-        // two rows per trip with the roles of the two line registers swapped: no copy of a line per row
-        int r = 1;
-        for (; r + 1 < nr; r += 2) {
-            step(r, L1, L0, T{}, T{});
-            step(r + 1, L0, L1, T{}, T{});
-        }
-        if (r < nr) {
-            step(r, L1, L0, T{}, T{});
-            L1 = L0;
-        }
-        if (nr >= 1) {
-            step(nr, L1, L0, F{}, T{});
-            put(out_row, pending);
-        }
-        if constexpr (chroma_mode(MODE)) {
-            for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+        // rows [from, to) with a following line pair: two rows per trip with the roles of the two line registers swapped
+        // (no copy of a line per row); afterwards L1 is K[to] again
+        auto rows = [&](int from, int to, auto store_tag) __attribute__((always_inline)) {
+            int r = from;
+            for (; r + 1 < to; r += 2) {
+                step(r, L1, L0, T{}, T{}, store_tag);
+                step(r + 1, L0, L1, T{}, T{}, store_tag);
+            }
+            if (r < to) {
+                step(r, L1, L0, T{}, T{}, store_tag);
+                L1 = L0;
+            }
+        };
+        if constexpr (MODE == kLumaSpill) {
+            // the rows a chroma pass can see first, with the hand-off; the rest of the plane without
+            const int split = a.rows_out + 1 < nr ? a.rows_out + 1 : nr;
+            rows(1, split, T{});
+            rows(split, nr, F{});
+            if (nr >= 1) {
+                step(nr, L1, L0, F{}, T{}, T{});
+                put(out_row, pending);
+            }
+        } else {
+            rows(1, nr, F{});
+            if (nr >= 1) {
+                step(nr, L1, L0, F{}, T{}, F{});
+                put(out_row, pending);
+            }
+            if constexpr (chroma_mode(MODE)) {
+                for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{}, F{});
+            }
         }
     }
 
