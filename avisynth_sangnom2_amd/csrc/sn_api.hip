@@ -17,7 +17,11 @@
 #include "sn_copier.h"
 #include "sn_internal.h"
 
+constexpr int kSyncChunks = 4;  // chunks of rows a pageable plane of the synchronous call is staged in
+
 namespace sn {
+
+
 
 struct Context {
     sn_config cfg{};
@@ -100,6 +104,11 @@ struct Context {
     uint8_t* stage_dst[3] = {nullptr, nullptr, nullptr};
     int stage_src_pitch[3] = {0, 0, 0};
     int stage_dst_pitch[3] = {0, 0, 0};
+    // pinned host staging of the synchronous call for planes in PAGEABLE memory: the lines that travel, compact, at the
+    // device staging's pitch (kept lines in, interpolated lines out).  The runtime never sees a pageable pointer.
+    uint8_t* sync_in[3] = {nullptr, nullptr, nullptr};
+    uint8_t* sync_out[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t sync_back[3][kSyncChunks] = {};  // chunk k of plane p's interpolated lines has arrived in sync_out[p]
 
     int64_t frames = 0, fused_frames = 0;
     std::string err;
@@ -326,6 +335,10 @@ void sn_destroy(sn_context* h)
     for (int p = 0; p < 3; ++p) {
         if (c->stage_src[p]) (void)hipFree(c->stage_src[p]);
         if (c->stage_dst[p]) (void)hipFree(c->stage_dst[p]);
+        if (c->sync_in[p]) (void)hipHostFree(c->sync_in[p]);
+        if (c->sync_out[p]) (void)hipHostFree(c->sync_out[p]);
+        for (int k = 0; k < kSyncChunks; ++k)
+            if (c->sync_back[p][k]) (void)hipEventDestroy(c->sync_back[p][k]);
     }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -550,6 +563,7 @@ static int field_offset(const Context* c, int parity)
 struct KeptLines {
     int first, step, rows;
 };
+
 static KeptLines kept_lines(const Context* c, int p, int parity)
 {
     if (c->cfg.dh || !c->process[p]) return {0, 1, c->plane_h_in(p)};
@@ -1242,8 +1256,12 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
                                 (size_t)c->stage_src_pitch[p] * c->plane_h_in(p)));
             SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_dst[p]),
                                 (size_t)c->stage_dst_pitch[p] * c->plane_h_out(p)));
+            SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->sync_in[p]), (size_t)c->stage_src_pitch[p] * c->plane_h_in(p), hipHostMallocDefault));
+            SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->sync_out[p]), (size_t)c->stage_dst_pitch[p] * (c->plane_h_out(p) / 2 + 1), hipHostMallocDefault));
+            for (int k = 0; k < kSyncChunks; ++k) SN_HIP(c, hipEventCreateWithFlags(&c->sync_back[p][k], hipEventDisableTiming));
         }
     }
+    ensure_copier(c);
     // Several planes: the copies go on streams of their own, so that plane p + 1 arrives and plane p - 1 leaves while plane
     // p is in the kernels (a 2160p YUV420P8 call: 1.16 -> 0.9 ms).  One plane: everything in order on the context's stream.
     Context::PlaneGate& g = c->gate;
@@ -1257,16 +1275,35 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
         }
     }
     for (int p = 0; p < c->nplanes(); ++p) {
-        // (a plane inside memory the caller pinned is DMA'd as it lies; a pageable one goes through the runtime's own
-        // staging -- either way one call)
         if (!(c->cfg.dh || c->process[p])) {  // a copied plane never visits the device: the host copies it (kept_line_jobs below)
             if (piped) SN_HIP(c, hipEventRecord(g.arrived[p], g.in));
             continue;
         }
         const KeptLines kl = kept_lines(c, p, parity);
-        SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p] + (int64_t)kl.first * c->stage_src_pitch[p], (size_t)kl.step * c->stage_src_pitch[p],
-                                   static_cast<const uint8_t*>(src[p]) + (int64_t)kl.first * sp[p], (size_t)kl.step * sp[p],
-                                   (size_t)c->plane_w(p) * B, kl.rows, hipMemcpyHostToDevice, piped ? g.in : c->stream));
+        const uint8_t* from = static_cast<const uint8_t*>(src[p]) + (int64_t)kl.first * sp[p];
+        size_t from_pitch = (size_t)kl.step * sp[p];
+        if (!sn::plane_is_pinned(src[p], sp[p], c->plane_w(p) * B, c->plane_h_in(p))) {
+            // A plane in pageable memory: the host's copy threads bring the lines that travel into the context's pinned
+            // staging first (while the previous plane is on the link).  Rounds 1-2 handed the caller's pointer to
+            // hipMemcpy2DAsync and left pinning or staging to the runtime; that path produced "DMA buffer failed"
+            // fall-backs and, once in a few hundred calls in a long-lived process, a GPU access fault at an address of the
+            // caller's heap (profiles/r3_page_fault.md).  A plane inside memory the caller pinned is DMA'd as it lies.
+            // in a few chunks of rows, so that a chunk crosses PCIe while the threads copy the next one
+            const int chunks = kl.rows >= 4 * kSyncChunks ? kSyncChunks : 1;
+            for (int k = 0; k < chunks; ++k) {
+                const int y0 = (int)((int64_t)kl.rows * k / chunks), y1 = (int)((int64_t)kl.rows * (k + 1) / chunks);
+                const Copier::Job job = {c->sync_in[p] + (size_t)y0 * c->stage_src_pitch[p], from + (size_t)y0 * from_pitch, c->stage_src_pitch[p],
+                                         (int)from_pitch, c->plane_w(p) * B, y1 - y0};
+                c->copier->run(&job, 1);
+                SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p] + ((int64_t)kl.first + (int64_t)y0 * kl.step) * c->stage_src_pitch[p],
+                                           (size_t)kl.step * c->stage_src_pitch[p], c->sync_in[p] + (size_t)y0 * c->stage_src_pitch[p],
+                                           (size_t)c->stage_src_pitch[p], (size_t)c->plane_w(p) * B, y1 - y0, hipMemcpyHostToDevice,
+                                           piped ? g.in : c->stream));
+            }
+        } else {
+            SN_HIP(c, hipMemcpy2DAsync(c->stage_src[p] + (int64_t)kl.first * c->stage_src_pitch[p], (size_t)kl.step * c->stage_src_pitch[p],
+                                       from, from_pitch, (size_t)c->plane_w(p) * B, kl.rows, hipMemcpyHostToDevice, piped ? g.in : c->stream));
+        }
         if (piped) SN_HIP(c, hipEventRecord(g.arrived[p], g.in));
     }
     const void* dsrc[3] = {c->stage_src[0], c->stage_src[1], c->stage_src[2]};
@@ -1288,6 +1325,7 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
         ensure_copier(c);
         c->copier->run(jobs, nj);
     }
+    bool staged_back[3] = {false, false, false};
     for (int p = 0; p < c->nplanes(); ++p) {
         if (piped) {
             if (!g.recorded[p]) SN_HIP(c, hipEventRecord(g.done[p], c->stream));  // a path that is not written plane by plane: all done here
@@ -1295,10 +1333,37 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
         }
         // only the interpolated lines come back: offset + 1, offset + 3, ... (nr of them)
         const int off = field_offset(c, parity), nr = c->plane_h_out(p) / 2 - 1;
-        if ((c->cfg.dh || c->process[p]) && nr > 0)
-            SN_HIP(c, hipMemcpy2DAsync(static_cast<uint8_t*>(dst[p]) + (int64_t)(off + 1) * dp[p], (size_t)2 * dp[p],
-                                       c->stage_dst[p] + (int64_t)(off + 1) * c->stage_dst_pitch[p], (size_t)2 * c->stage_dst_pitch[p],
-                                       (size_t)c->plane_w(p) * B, nr, hipMemcpyDeviceToHost, piped ? g.out : c->stream));
+        staged_back[p] = false;
+        if ((c->cfg.dh || c->process[p]) && nr > 0) {
+            hipStream_t so = piped ? g.out : c->stream;
+            const uint8_t* from = c->stage_dst[p] + (int64_t)(off + 1) * c->stage_dst_pitch[p];
+            if (!sn::plane_is_pinned(dst[p], dp[p], c->plane_w(p) * B, c->plane_h_out(p))) {  // pageable: through the pinned staging, in chunks
+                staged_back[p] = true;
+                const int chunks = nr >= 4 * kSyncChunks ? kSyncChunks : 1;
+                for (int k = 0; k < chunks; ++k) {
+                    const int y0 = (int)((int64_t)nr * k / chunks), y1 = (int)((int64_t)nr * (k + 1) / chunks);
+                    SN_HIP(c, hipMemcpy2DAsync(c->sync_out[p] + (size_t)y0 * c->stage_dst_pitch[p], (size_t)c->stage_dst_pitch[p],
+                                               from + (size_t)y0 * 2 * c->stage_dst_pitch[p], (size_t)2 * c->stage_dst_pitch[p],
+                                               (size_t)c->plane_w(p) * B, y1 - y0, hipMemcpyDeviceToHost, so));
+                    SN_HIP(c, hipEventRecord(c->sync_back[p][k], so));
+                }
+            } else {
+                SN_HIP(c, hipMemcpy2DAsync(static_cast<uint8_t*>(dst[p]) + (int64_t)(off + 1) * dp[p], (size_t)2 * dp[p], from,
+                                           (size_t)2 * c->stage_dst_pitch[p], (size_t)c->plane_w(p) * B, nr, hipMemcpyDeviceToHost, so));
+            }
+        }
+    }
+    for (int p = 0; p < c->nplanes(); ++p) {  // the staged planes: from the pinned staging into the caller's lines, chunk by chunk as they arrive
+        if (!staged_back[p]) continue;
+        const int off = field_offset(c, parity), nr = c->plane_h_out(p) / 2 - 1;
+        const int chunks = nr >= 4 * kSyncChunks ? kSyncChunks : 1;
+        for (int k = 0; k < chunks; ++k) {
+            const int y0 = (int)((int64_t)nr * k / chunks), y1 = (int)((int64_t)nr * (k + 1) / chunks);
+            SN_HIP(c, hipEventSynchronize(c->sync_back[p][k]));
+            const Copier::Job job = {static_cast<uint8_t*>(dst[p]) + (size_t)(off + 1 + 2 * y0) * dp[p], c->sync_out[p] + (size_t)y0 * c->stage_dst_pitch[p],
+                                     2 * dp[p], c->stage_dst_pitch[p], c->plane_w(p) * B, y1 - y0};
+            c->copier->run(&job, 1);
+        }
     }
     if (piped) SN_HIP(c, hipStreamSynchronize(g.out));
     SN_HIP(c, hipStreamSynchronize(c->stream));
@@ -1533,7 +1598,8 @@ int sn_collect_host(sn_context* h, int32_t slot, void* const dst_arg[3], const i
         if (sd.direct[p] && dst[p] == sd.ptr[p]) continue;  // already written there by the device
         const uint8_t* from = c->ring_pin_out[p] + (int64_t)slot * c->ring_bytes_out[p];
         if (sd.direct[p]) {  // collected into another place than announced: that plane never reached the staging
-            SN_HIP(c, hipMemcpy2D(dst[p], dp[p], sd.ptr[p], sd.pitch[p], (size_t)c->plane_w(p) * B, c->plane_h_out(p), hipMemcpyHostToHost));
+            for (int y = 0; y < c->plane_h_out(p); ++y)  // host to host: no business of the runtime's
+                memcpy(static_cast<uint8_t*>(dst[p]) + (size_t)y * dp[p], static_cast<const uint8_t*>(sd.ptr[p]) + (size_t)y * sd.pitch[p], (size_t)c->plane_w(p) * B);
             continue;
         }
         // (sd.kept_on_host implies direct[p] for every plane: handled above)
@@ -1726,6 +1792,8 @@ struct sn_aa_context {
     uint8_t* d_u1[3] = {nullptr, nullptr, nullptr};   // turned: its output
     uint8_t* d_t2[3] = {nullptr, nullptr, nullptr};   // clip geometry: input of the second pass
     uint8_t* d_out[3] = {nullptr, nullptr, nullptr};
+    uint8_t* h_src[3] = {nullptr, nullptr, nullptr};  // pinned staging for planes the caller holds in pageable memory
+    uint8_t* h_dst[3] = {nullptr, nullptr, nullptr};
     std::string err;
 };
 
@@ -1743,6 +1811,9 @@ void sn_aa_destroy(sn_aa_context* a)
     for (int p = 0; p < 3; ++p)
         for (uint8_t* q : {a->d_src[p], a->d_t1[p], a->d_u1[p], a->d_t2[p], a->d_out[p]})
             if (q) (void)hipFree(q);
+    for (int p = 0; p < 3; ++p)
+        for (uint8_t* q : {a->h_src[p], a->h_dst[p]})
+            if (q) (void)hipHostFree(q);
     delete a;
 }
 
@@ -1789,6 +1860,8 @@ int sn_aa_create_with_policy(const sn_config* cfg, const sn_policy* policy, sn_a
         const size_t clip_bytes = (size_t)a->pitch[p] * a->h[p], turned_bytes = (size_t)a->tpitch[p] * a->w[p];
         for (uint8_t** q : {&a->d_src[p], &a->d_t2[p], &a->d_out[p]})
             if (hipMalloc(reinterpret_cast<void**>(q), clip_bytes) != hipSuccess) return fail_aa(a, SN_ERR_HIP, "hipMalloc failed (sn_aa_create)");
+        for (uint8_t** q : {&a->h_src[p], &a->h_dst[p]})
+            if (hipHostMalloc(reinterpret_cast<void**>(q), clip_bytes, hipHostMallocDefault) != hipSuccess) return fail_aa(a, SN_ERR_HIP, "hipHostMalloc failed (sn_aa_create)");
         for (uint8_t** q : {&a->d_t1[p], &a->d_u1[p]})
             if (hipMalloc(reinterpret_cast<void**>(q), turned_bytes) != hipSuccess) return fail_aa(a, SN_ERR_HIP, "hipMalloc failed (sn_aa_create)");
     }
@@ -1818,8 +1891,19 @@ int sn_aa_process_host(sn_aa_context* a, const void* const src[3], const int32_t
     SN_AA_HIP(hipSetDevice(a->cfg.device));
     SN_AA_SN(a->first, prepare_small_launch_scratch(reinterpret_cast<Context*>(a->first)));
     SN_AA_SN(a->second, prepare_small_launch_scratch(reinterpret_cast<Context*>(a->second)));
-    for (int p = 0; p < a->planes; ++p)
-        SN_AA_HIP(hipMemcpy2DAsync(a->d_src[p], a->pitch[p], src[p], sp[p], (size_t)a->w[p] * B, a->h[p], hipMemcpyHostToDevice, a->stream));
+    // planes in pageable memory go through the context's pinned staging (the runtime never sees a pageable pointer, see
+    // sn_process_host); planes inside memory the caller pinned are DMA'd as they lie
+    for (int p = 0; p < a->planes; ++p) {
+        const void* from = src[p];
+        size_t from_pitch = (size_t)sp[p];
+        if (!sn::plane_is_pinned(src[p], sp[p], a->w[p] * B, a->h[p])) {
+            for (int y = 0; y < a->h[p]; ++y)
+                memcpy(a->h_src[p] + (size_t)y * a->pitch[p], static_cast<const uint8_t*>(src[p]) + (size_t)y * sp[p], (size_t)a->w[p] * B);
+            from = a->h_src[p];
+            from_pitch = (size_t)a->pitch[p];
+        }
+        SN_AA_HIP(hipMemcpy2DAsync(a->d_src[p], a->pitch[p], from, from_pitch, (size_t)a->w[p] * B, a->h[p], hipMemcpyHostToDevice, a->stream));
+    }
     for (int p = 0; p < a->planes; ++p)  // TurnLeft
         SN_AA_SN(a->first, sn_turn_device(a->first, -1, 1, a->d_src[p], 0, a->pitch[p], a->w[p], a->h[p], a->d_t1[p], 0, a->tpitch[p]));
     {
@@ -1834,9 +1918,17 @@ int sn_aa_process_host(sn_aa_context* a, const void* const src[3], const int32_t
         void* d3[3] = {a->d_out[0], a->d_out[1], a->d_out[2]};
         SN_AA_SN(a->second, sn_process_device(a->second, s3, a->pitch, d3, a->pitch, parity));
     }
-    for (int p = 0; p < a->planes; ++p)
-        SN_AA_HIP(hipMemcpy2DAsync(dst[p], dp[p], a->d_out[p], a->pitch[p], (size_t)a->w[p] * B, a->h[p], hipMemcpyDeviceToHost, a->stream));
+    bool staged[3] = {false, false, false};
+    for (int p = 0; p < a->planes; ++p) {
+        staged[p] = !sn::plane_is_pinned(dst[p], dp[p], a->w[p] * B, a->h[p]);
+        SN_AA_HIP(hipMemcpy2DAsync(staged[p] ? a->h_dst[p] : dst[p], staged[p] ? (size_t)a->pitch[p] : (size_t)dp[p], a->d_out[p], a->pitch[p],
+                                   (size_t)a->w[p] * B, a->h[p], hipMemcpyDeviceToHost, a->stream));
+    }
     SN_AA_HIP(hipStreamSynchronize(a->stream));
+    for (int p = 0; p < a->planes; ++p)
+        if (staged[p])
+            for (int y = 0; y < a->h[p]; ++y)
+                memcpy(static_cast<uint8_t*>(dst[p]) + (size_t)y * dp[p], a->h_dst[p] + (size_t)y * a->pitch[p], (size_t)a->w[p] * B);
 #undef SN_AA_HIP
 #undef SN_AA_SN
     return SN_OK;

@@ -433,17 +433,32 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs po
 // round earlier when the lag is three rounds.
 constexpr int kChainLag = 3;
 
-__global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
+// Round 3: TWO passes per wave.  A 32-bit register holds column x of one pass in its low half and column x of the pass
+// that follows it in the chain (three blocks behind) in its high half -- the packing of the fused 8-bit sweeps, with two
+// passes where those have two strips -- so one instruction stream smooths a row of each: eight packed registers per lane,
+// three-row sums, DPP for the neighbours, a sliding box, `(sum >> 4) & 0x00ff00ff`.  76 instructions per lane and round
+// row for sixteen columns where the one-pass body took 75 for eight; the workgroup is bound by what its CU issues, so the
+// chain runs twice as fast.  The halves are at different rows of different pool slots: each has its own pointers, fetch
+// ring, fresh-row count, and its loads, stores, ghost refresh and first-rows round are masked per half.  The mailbox is
+// indexed by the parity of the ROUND (both halves publish and receive at the same barrier), not of a pass's block.
+#ifndef SN_CHAIN8_THREADS
+#define SN_CHAIN8_THREADS 1024  // sixteen waves, four per SIMD: the two-pass body fits 128 registers (512 threads measured slower)
+#endif
+constexpr int kChain8Threads = SN_CHAIN8_THREADS;
+__global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
                                                                     int cycle)
 {
     using namespace v3c;
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr unsigned kLo = 0x0000ffffu, kHi = 0xffff0000u;
     const int se = pool.stride_e;
     const int nl = se >> 3;  // lanes that own columns
     const int b = blockIdx.x;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int ps = (tid >> 6) / nw, wave = (tid >> 6) % nw;  // which pass of the `lanes` in flight, which strip of it
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler must know it: everything
+    const int pair = wid / nw, wave = wid % nw;                // the schedule derives from it then lives in scalar registers
+    // (pair: which pair of the passes in flight; wave: which strip of it)
     int gl;
     bool ghost;
     if (wave == 0) {
@@ -455,108 +470,164 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_chain(PoolArgs poo
     }
     const bool live = gl < nl, real = live && !ghost;
     const int x0 = live ? gl * 8 : 0;  // dead lanes shadow column 0 and store nothing
-    const unsigned first_mask = live && gl == 0 ? 0xffffffffu : 0u, last_mask = live && gl == nl - 1 ? 0xffffffffu : 0u;
-    // mailbox: [pass in flight][copy][wave][side][slot][4 registers]
-    unsigned* mb = reinterpret_cast<unsigned*>(smem) + (size_t)ps * (2 * nw * 2 * GH * 4);
-    auto mb_at = [&](int copy, int w, int side, int slot) { return mb + ((((copy * nw + w) * 2 + side) * GH + slot) * 4); };
+    const unsigned last_mask = live && gl == nl - 1 ? 0xffffffffu : 0u;
+    // mailbox: [pair in flight][copy][wave][side][slot][8 packed registers]
+    unsigned* mb = reinterpret_cast<unsigned*>(smem) + (size_t)pair * (2 * nw * 2 * GH * 8);
+    auto mb_at = [&](int copy, int w, int side, int slot) { return mb + ((((copy * nw + w) * 2 + side) * GH + slot) * 8); };
     const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < nw - 1;
     const bool pub_left = lane >= GH && lane < 2 * GH && wave > 0;
     const bool recv = ghost && live;
     const int slot = lane < GH ? lane : lane >= 64 - GH ? lane - (64 - GH) : pub_right ? lane - (64 - 2 * GH) : lane - GH;
 
     struct Row {
-        unsigned v[4];  // columns x0 + 2i | x0 + 2i + 1 << 16
+        unsigned v[8];  // column x0 + c of the low-half pass | of the high-half pass << 16
     };
-    auto unpack = [](uint2 q) {
+    auto unpack = [](uint2 lo, uint2 hi) {  // byte k of the lo words -> bits 0..7, of the hi words -> bits 16..23
         Row r;
-        r.v[0] = __builtin_amdgcn_perm(0u, q.x, 0x0c010c00u);
-        r.v[1] = __builtin_amdgcn_perm(0u, q.x, 0x0c030c02u);
-        r.v[2] = __builtin_amdgcn_perm(0u, q.y, 0x0c010c00u);
-        r.v[3] = __builtin_amdgcn_perm(0u, q.y, 0x0c030c02u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r.v[k] = __builtin_amdgcn_perm(hi.x, lo.x, 0x0c040c00u + (unsigned)k * 0x00010001u);
+            r.v[4 + k] = __builtin_amdgcn_perm(hi.y, lo.y, 0x0c040c00u + (unsigned)k * 0x00010001u);
+        }
         return r;
     };
     const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
     const int ncycles = (ch.npass + lanes - 1) / lanes;
     const int total = (ncycles - 1) * cycle + (lanes - 1) * kChainLag + pass_rounds;
 
-    // state of the pass this wave is working on
-    const uint8_t* own = nullptr;   // this lane's columns in the pass's slot ...
-    const uint8_t* before = nullptr;  // ... and in the slot of the pass before it
-    uint8_t* out = nullptr;
-    int fresh_rows = 0;  // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
-    Row prev{}, cur{}, nxt{};
+    // state of the two passes this wave is working on (lo: low halves, pass slot 2 * pair; hi: high halves)
+    struct Half {
+        const uint8_t* own;     // this lane's columns in the pass's slot ...
+        const uint8_t* before;  // ... and in the slot of the pass before it
+        uint8_t* out;
+        int fresh_rows;         // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
+        int t;                  // block of K rows the pass is at in this round
+        bool run;
+        uint2 ring[K];          // rows fetched ahead
+    };
     constexpr int kAhead = K;
-    uint2 ring[kAhead] = {};
-    auto load = [&](int row) {
-        row = row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
-        const uint8_t* from = row >= 1 && row <= fresh_rows ? own : before;
+    const uint8_t* idle = pool.base + (size_t)b * bufsz + x0;  // somewhere mapped for the loads of a half without a pass
+    Half lo{idle, idle, nullptr, 0, 0, false, {}}, hi{idle, idle, nullptr, 0, 0, false, {}};
+    Row prev{}, cur{}, nxt{};
+    auto load = [&](const Half& H, int row) {
+        row = row < 0 ? 0 : row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
+        const uint8_t* from = row >= 1 && row <= H.fresh_rows ? H.own : H.before;
         return *reinterpret_cast<const uint2*>(from + (size_t)row * se);
+    };
+    // where a pass slot stands in this round; fetches the pass's first rows into its half of the registers
+    auto schedule = [&](Half& H, int ps, bool high, int round) {
+        const int rel = round - ps * kChainLag;
+        const int j = rel >= 0 ? (rel / cycle) * lanes + ps : ch.npass;
+        H.t = rel >= 0 ? rel % cycle - 1 : 0;
+        const bool active = j < ch.npass && H.t < pass_rounds - 1;
+        H.run = active && H.t >= 0;
+        if (active && H.t < 0) {
+            const int k = j % ch.pn;
+            const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
+            H.own = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
+            H.before = pool.base + s_before * pool.slot_bytes + (size_t)b * bufsz + x0;
+            H.out = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
+            H.fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
+            const uint2 z = make_uint2(0u, 0u);
+            const uint2 q0 = load(H, 0), q1 = load(H, 1), q2 = load(H, 2);
+            const Row p0 = high ? unpack(z, q0) : unpack(q0, z), p1 = high ? unpack(z, q1) : unpack(q1, z), p2 = high ? unpack(z, q2) : unpack(q2, z);
+            const unsigned keep = high ? kLo : kHi;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                prev.v[c] = (prev.v[c] & keep) | p0.v[c];
+                cur.v[c] = (cur.v[c] & keep) | p1.v[c];
+                nxt.v[c] = (nxt.v[c] & keep) | p2.v[c];
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) H.ring[u] = load(H, 3 + u);
+        }
     };
 
     for (int round = 0; round < total; ++round) {
         __syncthreads();
-        const int rel = round - ps * kChainLag;
-        if (rel < 0) continue;
-        const int j = (rel / cycle) * lanes + ps, t = rel % cycle - 1;
-        if (j >= ch.npass || t >= pass_rounds - 1) continue;
-        if (t < 0) {  // the pass's first rows
-            const int k = j % ch.pn;
-            const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
-            own = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
-            before = pool.base + s_before * pool.slot_bytes + (size_t)b * bufsz + x0;
-            out = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
-            fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
-            prev = unpack(load(0));
-            cur = unpack(load(1));
-            nxt = unpack(load(2));
+        schedule(lo, 2 * pair, false, round);
+        schedule(hi, 2 * pair + 1, true, round);
+        if (!lo.run && !hi.run) continue;
+        const int copy = round & 1;
+        const unsigned refresh = (lo.run && lo.t > 0 ? kLo : 0u) | (hi.run && hi.t > 0 ? kHi : 0u);
+        if (refresh && recv) {  // the ghosts take over what the seam lanes held after the block before
+            const unsigned* from = mb_at(copy, wave, lane < GH ? 0 : 1, slot);
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) ring[u] = load(3 + u);
-            continue;
+            for (int c = 0; c < 8; ++c) prev.v[c] = (from[c] & refresh) | (prev.v[c] & ~refresh);
         }
-        if (t > 0 && recv) {  // the ghosts take over what the seam lanes held after the block before
-            const unsigned* from = mb_at(t & 1, wave, lane < GH ? 0 : 1, slot);
+        // one row of each pass; BOTH: both halves have a row here (known at compile time in the steady state)
+        auto row_body = [&](int u, bool v0, bool v1, auto both_tag) __attribute__((always_inline)) {
+            constexpr bool BOTH = decltype(both_tag)::value;
+            const int r0 = K * lo.t + 1 + u, r1 = K * hi.t + 1 + u;
+            const uint2 pre0 = lo.ring[u], pre1 = hi.ring[u];
+            if (BOTH || v0) lo.ring[u] = load(lo, r0 + 2 + kAhead);
+            if (BOTH || v1) hi.ring[u] = load(hi, r1 + 2 + kAhead);
+            unsigned E[8];  // three-row sums of the lane's eight columns, both passes
 #pragma unroll
-            for (int i = 0; i < 4; ++i) prev.v[i] = from[i];
-        }
+            for (int c = 0; c < 8; ++c) E[c] = prev.v[c] + cur.v[c] + nxt.v[c];
+            // the neighbouring lanes' sums; the pool row is clamped at both ends (SangNom2.cpp:144-150): column 0 is
+            // lane 0 of the first strip, whose DPP move keeps its `old` operand (lane 0 of the other strips is the
+            // outermost ghost lane); the last column takes a bitwise select (a DPP read must not run under a lane mask)
+            unsigned X[14];
 #pragma unroll
-        for (int u = 0; u < K; ++u) {
-            const int r = K * t + 1 + u;
-            if (r < rows) {  // uniform
-                const uint2 pre = ring[u];
-                ring[u] = load(r + 2 + kAhead);
-                unsigned E[8];  // as k_smooth_u8_strips
+            for (int k = 0; k < 3; ++k) {
+                X[k] = dpp_from_left_or(E[0], E[5 + k]);
+                X[11 + k] = (last_mask & E[7]) | (~last_mask & dpp_from_right(E[k]));
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) E[2 + i] = prev.v[i] + cur.v[i] + nxt.v[i];
-                const unsigned left_edge = (E[2] & 0xffffu) * 0x10001u, right_edge = (E[5] >> 16) * 0x10001u;
-                E[0] = (first_mask & left_edge) | (~first_mask & dpp_from_left(E[4]));
-                E[1] = (first_mask & left_edge) | (~first_mask & dpp_from_left(E[5]));
-                E[6] = (last_mask & right_edge) | (~last_mask & dpp_from_right(E[2]));
-                E[7] = (last_mask & right_edge) | (~last_mask & dpp_from_right(E[3]));
-                unsigned O[7];
+            for (int c = 0; c < 8; ++c) X[3 + c] = E[c];
+            unsigned T = ((X[0] + X[1]) + (X[2] + X[3])) + ((X[4] + X[5]) + X[6]);
+            Row o;
 #pragma unroll
-                for (int q = 0; q < 7; ++q) O[q] = __builtin_amdgcn_alignbit(E[q + 1], E[q], 16);
-                unsigned T = ((O[0] + E[1]) + (O[1] + E[2])) + ((O[2] + E[3]) + O[3]);
-                Row o;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    o.v[m] = (T >> 4) & 0x00ff00ffu;
-                    if (m < 3) T = (T - O[m] - E[1 + m]) + (E[4 + m] + O[m + 4]);
-                }
+            for (int c = 0; c < 8; ++c) {
+                o.v[c] = (T >> 4) & 0x00ff00ffu;  // (sum / 16) wraps to uint8_t, SangNom2.cpp:152; integer sums: any order
+                if (c < 7) T = (T - X[c]) + X[c + 7];
+            }
+            {   // o.v[c] = low-pass byte | high-pass byte << 16  ->  eight bytes per pass
+                const unsigned t01 = __builtin_amdgcn_perm(o.v[1], o.v[0], 0x06020400u), t23 = __builtin_amdgcn_perm(o.v[3], o.v[2], 0x06020400u);
+                const unsigned t45 = __builtin_amdgcn_perm(o.v[5], o.v[4], 0x06020400u), t67 = __builtin_amdgcn_perm(o.v[7], o.v[6], 0x06020400u);
+                uint2 qa, qb;
+                qa.x = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+                qa.y = __builtin_amdgcn_perm(t67, t45, 0x05040100u);
+                qb.x = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+                qb.y = __builtin_amdgcn_perm(t67, t45, 0x07060302u);
                 if (real) {
-                    uint2 q;
-                    q.x = __builtin_amdgcn_perm(o.v[1], o.v[0], 0x06040200u);
-                    q.y = __builtin_amdgcn_perm(o.v[3], o.v[2], 0x06040200u);
-                    *reinterpret_cast<uint2*>(out + (size_t)r * se) = q;
+                    if (BOTH || v0) *reinterpret_cast<uint2*>(lo.out + (size_t)r0 * se) = qa;
+                    if (BOTH || v1) *reinterpret_cast<uint2*>(hi.out + (size_t)r1 * se) = qb;
                 }
+            }
+            if (BOTH || (v0 && v1)) {
                 prev = o;
                 cur = nxt;
-                nxt = unpack(pre);
+                nxt = unpack(pre0, pre1);
+            } else {
+                // a half that has no row here -- its pass has just fetched its first rows, or is over -- keeps its
+                // registers (carries never cross the halves: every quantity stays below 2^16 whatever a half holds)
+                const unsigned m = v0 ? kLo : kHi;
+                const Row nn = unpack(pre0, pre1);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    prev.v[c] = (o.v[c] & m) | (prev.v[c] & ~m);
+                    cur.v[c] = (nxt.v[c] & m) | (cur.v[c] & ~m);
+                    nxt.v[c] = (nn.v[c] & m) | (nxt.v[c] & ~m);
+                }
+            }
+        };
+        if (lo.run && hi.run && K * lo.t + K < rows && K * hi.t + K < rows) {  // the steady state: no condition per row
+#pragma unroll
+            for (int u = 0; u < K; ++u) row_body(u, true, true, std::integral_constant<bool, true>{});
+        } else {
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                const bool v0 = lo.run && K * lo.t + 1 + u < rows, v1 = hi.run && K * hi.t + 1 + u < rows;
+                if (v0 || v1) row_body(u, v0, v1, std::integral_constant<bool, false>{});  // uniform
             }
         }
-        if (K * (t + 1) < rows - 1 && (pub_right || pub_left)) {
-            unsigned* to = pub_right ? mb_at((t + 1) & 1, wave + 1, 0, slot) : mb_at((t + 1) & 1, wave - 1, 1, slot);
+        const bool more0 = lo.run && K * (lo.t + 1) < rows - 1, more1 = hi.run && K * (hi.t + 1) < rows - 1;
+        if ((more0 || more1) && (pub_right || pub_left)) {
+            unsigned* to = pub_right ? mb_at((round + 1) & 1, wave + 1, 0, slot) : mb_at((round + 1) & 1, wave - 1, 1, slot);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) to[i] = prev.v[i];
+            for (int c = 0; c < 8; ++c) to[c] = prev.v[c];
         }
     }
 }
@@ -1414,7 +1485,8 @@ int pool_chain_lanes(int bytes, int stride_e)
 {
     if (stride_e < 64) return 0;
     const int nw = v3c::strips_for(stride_e / 8);
-    return nw <= kSmoothThreads / 128 ? kSmoothThreads / 64 / nw : 0;  // at least two passes in flight
+    if (bytes == 1) return nw <= kChain8Threads / 64 ? 2 * (kChain8Threads / 64 / nw) : 0;  // two passes per set of nw waves (k_smooth_u8_chain)
+    return nw <= kSmoothThreads / 128 ? kSmoothThreads / 64 / nw : 0;                     // at least two passes in flight
 }
 
 template <class T>
@@ -1467,13 +1539,14 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
     const int nw = v3c::strips_for(pool.stride_e / 8);
     const int pass_rounds = 1 + (pool.bh - 1 + v3c::K - 1) / v3c::K;
     const int cycle = pass_rounds > lanes * kChainLag ? pass_rounds : lanes * kChainLag;
-    const size_t lds = (size_t)lanes * 2 * nw * 2 * v3c::GH * (bytes >= 2 ? 8 : 4) * sizeof(unsigned);
+    const int sets = bytes == 1 ? lanes / 2 : lanes;  // sets of nw waves (8-bit: a set carries two passes)
+    const size_t lds = (size_t)sets * 2 * nw * 2 * v3c::GH * 8 * sizeof(unsigned);
     if (bytes == 4)
         hipLaunchKernelGGL(k_smooth_f32_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else if (bytes == 2)
         hipLaunchKernelGGL(k_smooth_u16_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else
-        hipLaunchKernelGGL(k_smooth_u8_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+        hipLaunchKernelGGL(k_smooth_u8_chain, dim3(kBuffers), dim3(sets * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     return hipGetLastError();
 }
 
