@@ -119,6 +119,8 @@ struct Context {
     // the chain of a history-carrying stream (run_chain): a ring of pool slots, one per pass in flight
     uint8_t* chain_base = nullptr;
     int chain_slots = 0, chain_origin = 0;
+    uint32_t* chain_flags = nullptr;   // 8-bit chains over several workgroups per buffer: their round counters (device) ...
+    uint32_t* chain_status = nullptr;  // ... and the word a workgroup raises when it gave up waiting (host memory the device writes)
     int64_t chained_frames = 0;
     uint32_t* band_state = nullptr;
     int32_t* band_flags = nullptr;
@@ -304,6 +306,8 @@ void sn_destroy(sn_context* h)
         if (g.stream) (void)hipStreamSynchronize(g.stream);
     if (c->pool.base) (void)hipFree(c->pool.base);
     if (c->chain_base) (void)hipFree(c->chain_base);
+    if (c->chain_flags) (void)hipFree(c->chain_flags);
+    if (c->chain_status) (void)hipHostFree(c->chain_status);
     for (int p = 0; p < 3; ++p)
         if (c->plane_pool[p].base) (void)hipFree(c->plane_pool[p].base);
     for (int i = 0; i < 2; ++i)
@@ -517,7 +521,8 @@ static const char* policy_text(const sn_policy* p)
     if (!p) return nullptr;
     if (p->struct_size != (int32_t)sizeof(sn_policy)) return "sn_policy.struct_size mismatch";
     if (p->small_launches != SN_SMALL_AUTO && p->small_launches != SN_SMALL_SWEEP) return "sn_policy.small_launches must be SN_SMALL_AUTO or SN_SMALL_SWEEP";
-    if (p->chain != 0 && p->chain != -1) return "sn_policy.chain must be 0 (on) or -1 (off)";
+    if (p->chain != 0 && p->chain != -1 && p->chain != 1 && p->chain != 2 && p->chain != 4 && p->chain != 8)
+        return "sn_policy.chain must be 0 (on), -1 (off), or 1, 2, 4, 8 (workgroups per buffer of an 8-bit chain)";
     if (p->copy_threads < 0 || p->copy_threads > 16) return "sn_policy.copy_threads must be 0..16";
     if (p->scratch_budget_mb < 0) return "sn_policy.scratch_budget_mb must not be negative";
     return nullptr;
@@ -1074,6 +1079,12 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
 // flight, stage 3 of all passes.  The pool of slot 0 is where the chain starts and where its last pass's pool ends
 // up, so frames that come one at a time (and the pool's readers) carry on from there.
 constexpr int SN_CHAIN_UNAVAILABLE = -1000;  // internal: run_chain could not get its ring, run_batch falls back
+constexpr size_t kChainFlagBytes = (size_t)sn::kBuffers * sn::kChainMaxGroups * 32 * sizeof(uint32_t);
+#ifndef SN_CHAIN_DEFAULT_GROUPS
+#define SN_CHAIN_DEFAULT_GROUPS 4
+#endif
+constexpr int kChainDefaultGroups = SN_CHAIN_DEFAULT_GROUPS;  // sn_policy.chain = 0
+constexpr int kChainSlack = 2;  // rounds a workgroup's slots start later than lockstep with the workgroup before it would need
 
 static int chain_planes(const Context* c, int planes[3])
 {
@@ -1112,7 +1123,31 @@ static int ensure_chain(Context* c, int pn, hipStream_t st)
     }
     SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
     c->chain_origin = 0;
+    if (c->cfg.bytes_per_sample == 1) {
+        SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chain_flags), kChainFlagBytes));
+        SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->chain_status), sizeof(uint32_t), hipHostMallocDefault));
+        *c->chain_status = 0;
+    }
     return SN_OK;
+}
+
+// A workgroup of a chain over several workgroups gave up waiting for the one before it (sn_pool_kernels.hip,
+// k_smooth_u8_chain<true>): the frames of that launch are wrong.  Sticky: checked wherever the library has just waited for
+// the device, and before it queues anything else.
+static int chain_fault(Context* c)
+{
+    if (c->chain_status && __atomic_load_n(c->chain_status, __ATOMIC_RELAXED) != 0)
+        return sn::fail(c, SN_ERR_HIP, "a chain of passes timed out between two workgroups (sn_policy.chain = 1 keeps a buffer's chain on one workgroup); "
+                                       "the frames of that launch are invalid and the context must be recreated");
+    return SN_OK;
+}
+
+// workgroups per buffer for this context's chains
+static int chain_groups(const Context* c)
+{
+    int want = c->policy.chain > 0 ? c->policy.chain : kChainDefaultGroups;
+    if (const char* e = test_env("SN_CHAIN_GROUPS")) want = atoi(e);
+    return c->chain_flags ? sn::pool_chain_groups(c->cfg.bytes_per_sample, c->stride_e, want) : 1;
 }
 
 static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3], const int64_t sfs[3], const int32_t sp[3],
@@ -1161,6 +1196,13 @@ static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3]
         ch.npass = m * pn;
         ch.pn = pn;
         ch.origin = c->chain_origin;
+        ch.groups = chain_groups(c);
+        if (ch.groups > 1) {
+            ch.slack = kChainSlack;
+            ch.flags = c->chain_flags;
+            ch.status = c->chain_status;
+            SN_HIP(c, hipMemsetAsync(c->chain_flags, 0, kChainFlagBytes, st));
+        }
         for (int k = 0; k < pn; ++k) {
             sn::PlaneArgs a = pa[planes[k]];
             a.src += (int64_t)i * a.src_frame_stride;
@@ -1191,6 +1233,7 @@ static int run_batch(Context* c, hipStream_t st, int slot0, int nframes, const v
 {
     int f = 0;
     int planes[3] = {0, 0, 0};
+    if (int rc = chain_fault(c)) return rc;
     const int pn = slot0 == 0 ? chain_planes(c, planes) : 0;
     while (f < nframes) {
         const int off = field_offset(c, parity ? parity[f] : 1);
@@ -1371,7 +1414,7 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     // stream that is never synchronised keeps its commands -- and with them the runtime's transient registration of the
     // caller's pageable planes -- alive after the call has returned and the caller has freed or recycled that memory.
     if (piped) SN_HIP(c, hipStreamSynchronize(g.in));
-    return SN_OK;
+    return chain_fault(c);
 }
 
 // ---- the host ring: SURVEY 8(f)-1, pipelining behind GetFrame --------------------------------------------
@@ -1592,6 +1635,7 @@ int sn_collect_host(sn_context* h, int32_t slot, void* const dst_arg[3], const i
         if (rc != SN_OK) return rc;
     }
     SN_HIP(c, hipEventSynchronize(c->ring[gi].done));
+    if (int rc = chain_fault(c)) return rc;
     Copier::Job jobs[3];
     int njobs = 0;
     for (int p = 0; p < c->nplanes(); ++p) {
@@ -1674,7 +1718,7 @@ int sn_synchronize(sn_context* h)
     SN_HIP(c, hipStreamSynchronize(c->stream));
     for (auto& g : c->ring)
         if (g.stream) SN_HIP(c, hipStreamSynchronize(g.stream));
-    return SN_OK;
+    return chain_fault(c);
 }
 
 void* sn_get_stream(sn_context* h)

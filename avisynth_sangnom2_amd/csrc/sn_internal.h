@@ -43,10 +43,14 @@ struct PoolArgs {
 // Stage 2 of a history-carrying clip as a chain of passes (one per processed plane and frame, in the reference's
 // order): pass j smooths slot (origin + 1 + j) % slot_mod and takes every cell its own k_prepare did not write --
 // columns from w[j % pn] on, rows above nr[j % pn], row 0 -- from the slot of the pass before it.
+constexpr int kChainMaxGroups = 8;  // workgroups per buffer of an 8-bit chain (k_smooth_u8_chain<true>)
 struct ChainArgs {
     int32_t npass, pn;
     int32_t w[3], nr[3];
     int32_t origin;
+    int32_t groups, slack;  // 8-bit: workgroups per buffer (<= 1: one) and the rounds of slack between two of them
+    uint32_t* flags;        // groups > 1: kBuffers * kChainMaxGroups * 32 words, zero at launch (rounds completed per workgroup)
+    uint32_t* status;       // groups > 1: host-visible word, set when a workgroup stopped waiting for the one before it
 };
 
 struct Context;
@@ -60,6 +64,7 @@ hipError_t launch_assemble(hipStream_t s, const PlaneArgs& p, int bytes, int nfr
 hipError_t launch_pool_plane(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes,
                              double threshold, int nframes, int slot0);
 int pool_chain_lanes(int bytes, int stride_e);  // passes one workgroup keeps in flight; 0: no chain for this pool
+int pool_chain_groups(int bytes, int stride_e, int want);  // workgroups per buffer the chain kernel can run for `want`
 hipError_t launch_pool_prepare(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes, int nframes, int slot0);
 hipError_t launch_pool_finalize(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes, double threshold, int nframes,
                                 int slot0);

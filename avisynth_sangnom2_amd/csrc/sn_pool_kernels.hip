@@ -445,7 +445,34 @@ constexpr int kChainLag = 3;
 #define SN_CHAIN8_THREADS 1024  // sixteen waves, four per SIMD: the two-pass body fits 128 registers (512 threads measured slower)
 #endif
 constexpr int kChain8Threads = SN_CHAIN8_THREADS;
-__global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
+constexpr int kChainSpinLimit = 1 << 20;  // x (s_sleep 8 + a load from memory): two seconds and more
+
+// Round 3: SEVERAL workgroups per buffer (GROUPED).  One workgroup is bound by what its CU issues (profiles/r3_chain.md:
+// one VALU instruction per 4.7 cycles and SIMD where the instruction class's floor is 4.06), and a pass can only start
+// kChainLag rounds after the one before it -- so the stream's rate is 1 / (kChainLag x the time of a round), and a round
+// is as long as the waves of a SIMD are many.  With G workgroups a buffer's passes in flight are spread over G CUs (slots
+// g * lanes .. g * lanes + lanes - 1 in workgroup g, each with 1 / G of the sixteen waves): the rounds get shorter, the
+// passes in flight stay sixteen.  A slot's predecessor is in the same workgroup (the barrier orders the two, as before)
+// except for a workgroup's first slot, whose predecessor is the last slot of the workgroup before it (around the ring:
+// the first workgroup follows the last one's previous cycle).  That one hand-off goes through memory:
+//   * every pool access of the kernel is an agent-scope relaxed atomic (global_load / global_store ... sc1: coherent
+//     across the XCDs without cache maintenance.  Agent-scope FENCES cost 7 - 20 us per round here and the more the more
+//     workgroups issue them, the sc1 accesses 1.3 us when the reader sits waiting for them:
+//     tools/experiments/ubench_xwg_sync.hip, profiles/r3_chain.md);
+//   * a workgroup publishes "rounds completed" after its barrier (which waits for its stores), and the waves of its
+//     first slot start round R only when the workgroup before them has completed round R - 1 - slack.  The schedule
+//     starts workgroup g's slots g * slack rounds late, so in step that counter is `slack` rounds old news: the waves look
+//     at the value they fetched while the round before ran (a fresh poll is a trip to memory on the round's critical path,
+//     which cost 7 - 10 % of the rate with four and eight workgroups) and poll only if that is not enough;
+//   * a wait is bounded: after two seconds and more a workgroup gives up waiting for good and raises ChainArgs::status,
+//     which the host turns into an error (a workgroup that was never scheduled must not hang the GPU);
+//   * a pass's first rows come from memory as well: they are fetched at the start of the pass's first round and taken
+//     into the registers at its end (LATE_PRIME), not waited for on the spot.
+// 720x480 YUV420P8, 512 frames per launch: 23.1 k frames/s with one workgroup per buffer, 28.4 k with two, 31.5 k with
+// four (the default: 36 CUs), 32.9 k with eight.  Tried and dropped: fetching a round's rows all at its start into a
+// second ring (slower), waiting only for the stores of a round's first two rows at the barrier (no change).
+template <bool GROUPED>
+__global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads) k_smooth_u8_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
                                                                     int cycle)
 {
     using namespace v3c;
@@ -453,7 +480,9 @@ __global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs poo
     constexpr unsigned kLo = 0x0000ffffu, kHi = 0xffff0000u;
     const int se = pool.stride_e;
     const int nl = se >> 3;  // lanes that own columns
-    const int b = blockIdx.x;
+    constexpr bool LATE_PRIME = GROUPED;  // a pass's first rows are taken in at the END of its first round
+    const int groups = GROUPED ? ch.groups : 1, slack = GROUPED ? ch.slack : 0;
+    const int b = GROUPED ? (int)blockIdx.x / groups : (int)blockIdx.x, grp = GROUPED ? (int)blockIdx.x % groups : 0;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler must know it: everything
@@ -492,8 +521,9 @@ __global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs poo
         return r;
     };
     const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
-    const int ncycles = (ch.npass + lanes - 1) / lanes;
-    const int total = (ncycles - 1) * cycle + (lanes - 1) * kChainLag + pass_rounds;
+    const int slots = lanes * groups;  // passes in flight per buffer; slot g starts (g * kChainLag + its workgroup * slack) rounds in
+    const int ncycles = (ch.npass + slots - 1) / slots;
+    const int total = (ncycles - 1) * cycle + (slots - 1) * kChainLag + (groups - 1) * slack + pass_rounds;
 
     // state of the two passes this wave is working on (lo: low halves, pass slot 2 * pair; hi: high halves)
     struct Half {
@@ -502,52 +532,118 @@ __global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs poo
         uint8_t* out;
         int fresh_rows;         // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
         int t;                  // block of K rows the pass is at in this round
-        bool run;
+        bool run, fetch;        // the pass has rows in this round / is in its first round
         uint2 ring[K];          // rows fetched ahead
+        uint2 first[3];         // GROUPED: rows 0 .. 2, from the pass's first round's start to its end
     };
     constexpr int kAhead = K;
     const uint8_t* idle = pool.base + (size_t)b * bufsz + x0;  // somewhere mapped for the loads of a half without a pass
-    Half lo{idle, idle, nullptr, 0, 0, false, {}}, hi{idle, idle, nullptr, 0, 0, false, {}};
+    Half lo{idle, idle, nullptr, 0, 0, false, false, {}, {}}, hi{idle, idle, nullptr, 0, 0, false, false, {}, {}};
     Row prev{}, cur{}, nxt{};
     auto load = [&](const Half& H, int row) {
         row = row < 0 ? 0 : row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
         const uint8_t* from = row >= 1 && row <= H.fresh_rows ? H.own : H.before;
-        return *reinterpret_cast<const uint2*>(from + (size_t)row * se);
+        if constexpr (GROUPED) {
+            const unsigned long long q = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(from + (size_t)row * se), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            return make_uint2((unsigned)q, (unsigned)(q >> 32));
+        } else {
+            return *reinterpret_cast<const uint2*>(from + (size_t)row * se);
+        }
     };
-    // where a pass slot stands in this round; fetches the pass's first rows into its half of the registers
+    auto store = [&](uint8_t* to, uint2 q) {
+        if constexpr (GROUPED)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(to), (unsigned long long)q.x | (unsigned long long)q.y << 32, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        else
+            *reinterpret_cast<uint2*>(to) = q;
+    };
+    // a pass's rows 0 .. 2 into its half of the registers
+    auto prime_from = [&](uint2 q0, uint2 q1, uint2 q2, bool high) {
+        const uint2 z = make_uint2(0u, 0u);
+        const Row p0 = high ? unpack(z, q0) : unpack(q0, z), p1 = high ? unpack(z, q1) : unpack(q1, z), p2 = high ? unpack(z, q2) : unpack(q2, z);
+        const unsigned keep = high ? kLo : kHi;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            prev.v[c] = (prev.v[c] & keep) | p0.v[c];
+            cur.v[c] = (cur.v[c] & keep) | p1.v[c];
+            nxt.v[c] = (nxt.v[c] & keep) | p2.v[c];
+        }
+    };
+    auto prime = [&](const Half& H, bool high) { prime_from(H.first[0], H.first[1], H.first[2], high); };
+    // where a pass slot stands in this round; fetches the pass's first rows (one workgroup per buffer: into its half of
+    // the registers at once.  GROUPED: the loads come from memory, not from the L2, and a wave that sat through them would
+    // hold up its workgroup at the next barrier and the workgroups behind it: they are taken in when the round is over)
     auto schedule = [&](Half& H, int ps, bool high, int round) {
-        const int rel = round - ps * kChainLag;
-        const int j = rel >= 0 ? (rel / cycle) * lanes + ps : ch.npass;
+        const int g = grp * lanes + ps;  // the slot among all of the buffer's
+        const int rel = round - (g * kChainLag + grp * slack);
+        const int j = rel >= 0 ? (rel / cycle) * slots + g : ch.npass;
         H.t = rel >= 0 ? rel % cycle - 1 : 0;
         const bool active = j < ch.npass && H.t < pass_rounds - 1;
         H.run = active && H.t >= 0;
-        if (active && H.t < 0) {
+        H.fetch = active && H.t < 0;
+        if (H.fetch) {
             const int k = j % ch.pn;
             const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
             H.own = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
             H.before = pool.base + s_before * pool.slot_bytes + (size_t)b * bufsz + x0;
             H.out = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
             H.fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
-            const uint2 z = make_uint2(0u, 0u);
-            const uint2 q0 = load(H, 0), q1 = load(H, 1), q2 = load(H, 2);
-            const Row p0 = high ? unpack(z, q0) : unpack(q0, z), p1 = high ? unpack(z, q1) : unpack(q1, z), p2 = high ? unpack(z, q2) : unpack(q2, z);
-            const unsigned keep = high ? kLo : kHi;
+            if constexpr (LATE_PRIME) {  // only issued here: prime() takes them in when the round is over
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                prev.v[c] = (prev.v[c] & keep) | p0.v[c];
-                cur.v[c] = (cur.v[c] & keep) | p1.v[c];
-                nxt.v[c] = (nxt.v[c] & keep) | p2.v[c];
+                for (int u = 0; u < 3; ++u) H.first[u] = load(H, u);
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) H.ring[u] = load(H, 3 + u);
+            } else {
+                const uint2 q0 = load(H, 0), q1 = load(H, 1), q2 = load(H, 2);
+                prime_from(q0, q1, q2, high);
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) H.ring[u] = load(H, 3 + u);
             }
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) H.ring[u] = load(H, 3 + u);
         }
     };
 
+    unsigned* my_flag = nullptr;
+    const unsigned* his_flag = nullptr;
+    bool gave_up = false;
+    unsigned seen = 0;  // the round counter of the workgroup before this one, as last fetched
+    if constexpr (GROUPED) {
+        my_flag = ch.flags + (b * groups + grp) * 32;  // a cache line of 128 bytes each
+        his_flag = ch.flags + (b * groups + (grp + groups - 1) % groups) * 32;
+    }
     for (int round = 0; round < total; ++round) {
-        __syncthreads();
+        __syncthreads();  // (waits for this wave's stores and loads, then for everybody's)
+        if constexpr (GROUPED) {
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (tid == 0) __hip_atomic_store(my_flag, (unsigned)round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // rounds < round are complete
+            const int need = round - slack;  // ... of the workgroup before this one: what this round fetches from it is there then
+            if (pair == 0 && !gave_up) {
+                // `seen` was fetched while the round before this one ran (a poll is a trip to memory: on the round's critical
+                // path it would cost more than the round's arithmetic); in step it is `slack` rounds ahead of what is needed
+                if (need > 0 && (int)seen < need) {
+                    int spins = 0;
+                    while ((int)(seen = __hip_atomic_load(his_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                        if (++spins > kChainSpinLimit) {
+                            gave_up = true;
+                            __hip_atomic_store(ch.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                seen = __hip_atomic_load(his_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next round
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        }
         schedule(lo, 2 * pair, false, round);
         schedule(hi, 2 * pair + 1, true, round);
-        if (!lo.run && !hi.run) continue;
+        if (!lo.run && !hi.run) {
+            if constexpr (LATE_PRIME) {
+                if (lo.fetch) prime(lo, false);
+                if (hi.fetch) prime(hi, true);
+            }
+            continue;
+        }
         const int copy = round & 1;
         const unsigned refresh = (lo.run && lo.t > 0 ? kLo : 0u) | (hi.run && hi.t > 0 ? kHi : 0u);
         if (refresh && recv) {  // the ghosts take over what the seam lanes held after the block before
@@ -592,8 +688,8 @@ __global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs poo
                 qb.x = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
                 qb.y = __builtin_amdgcn_perm(t67, t45, 0x07060302u);
                 if (real) {
-                    if (BOTH || v0) *reinterpret_cast<uint2*>(lo.out + (size_t)r0 * se) = qa;
-                    if (BOTH || v1) *reinterpret_cast<uint2*>(hi.out + (size_t)r1 * se) = qb;
+                    if (BOTH || v0) store(lo.out + (size_t)r0 * se, qa);
+                    if (BOTH || v1) store(hi.out + (size_t)r1 * se, qb);
                 }
             }
             if (BOTH || (v0 && v1)) {
@@ -604,7 +700,9 @@ __global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs poo
                 // a half that has no row here -- its pass has just fetched its first rows, or is over -- keeps its
                 // registers (carries never cross the halves: every quantity stays below 2^16 whatever a half holds)
                 const unsigned m = v0 ? kLo : kHi;
-                const Row nn = unpack(pre0, pre1);
+                const uint2 z = make_uint2(0u, 0u);
+                // (LATE_PRIME: the ring of a half in its first round is still on its way)
+                const Row nn = LATE_PRIME ? unpack(v0 ? pre0 : z, v1 ? pre1 : z) : unpack(pre0, pre1);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     prev.v[c] = (o.v[c] & m) | (prev.v[c] & ~m);
@@ -621,6 +719,10 @@ __global__ void __launch_bounds__(kChain8Threads) k_smooth_u8_chain(PoolArgs poo
             for (int u = 0; u < K; ++u) {
                 const bool v0 = lo.run && K * lo.t + 1 + u < rows, v1 = hi.run && K * hi.t + 1 + u < rows;
                 if (v0 || v1) row_body(u, v0, v1, std::integral_constant<bool, false>{});  // uniform
+            }
+            if constexpr (LATE_PRIME) {
+                if (lo.fetch) prime(lo, false);
+                if (hi.fetch) prime(hi, true);
             }
         }
         const bool more0 = lo.run && K * (lo.t + 1) < rows - 1, more1 = hi.run && K * (hi.t + 1) < rows - 1;
@@ -1530,23 +1632,43 @@ hipError_t launch_pool_finalize(hipStream_t st, const PlaneArgs& p, const PoolAr
     return hipErrorInvalidValue;
 }
 
+// 8-bit chains: workgroups per buffer.  Each gets 1 / groups of the sixteen waves; a workgroup needs at least one pair of
+// passes (nw waves).
+int pool_chain_groups(int bytes, int stride_e, int want)
+{
+    if (bytes != 1 || want <= 1) return 1;
+    const int nw = v3c::strips_for(stride_e / 8);
+    int g = 1;
+    while (g * 2 <= want && g * 2 <= kChainMaxGroups && kChain8Threads / 64 / (g * 2) >= nw) g *= 2;
+    return g;
+}
+
 hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainArgs& chain, int bytes)
 {
-    const int lanes = pool_chain_lanes(bytes, pool.stride_e);
+    const int groups = chain.groups > 1 ? chain.groups : 1;
+    int lanes = pool_chain_lanes(bytes, pool.stride_e);
     if (lanes < 2 || pool.slot_mod <= chain.npass || chain.npass < 1 || pool.bh < 2) return hipErrorInvalidValue;
     for (int k = 0; k < chain.pn; ++k)
         if (chain.w[k] % 8 != 0 || chain.nr[k] >= pool.bh) return hipErrorInvalidValue;
     const int nw = v3c::strips_for(pool.stride_e / 8);
+    if (groups > 1) {
+        if (bytes != 1 || groups != pool_chain_groups(bytes, pool.stride_e, groups) || !chain.flags || !chain.status || chain.slack < 0)
+            return hipErrorInvalidValue;
+        lanes = 2 * (kChain8Threads / 64 / groups / nw);  // per workgroup: two passes per set of nw waves
+    }
     const int pass_rounds = 1 + (pool.bh - 1 + v3c::K - 1) / v3c::K;
-    const int cycle = pass_rounds > lanes * kChainLag ? pass_rounds : lanes * kChainLag;
+    const int busy = lanes * groups * kChainLag + groups * (groups > 1 ? chain.slack : 0);  // rounds until a slot may take its next pass
+    const int cycle = pass_rounds > busy ? pass_rounds : busy;
     const int sets = bytes == 1 ? lanes / 2 : lanes;  // sets of nw waves (8-bit: a set carries two passes)
     const size_t lds = (size_t)sets * 2 * nw * 2 * v3c::GH * 8 * sizeof(unsigned);
     if (bytes == 4)
         hipLaunchKernelGGL(k_smooth_f32_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else if (bytes == 2)
         hipLaunchKernelGGL(k_smooth_u16_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+    else if (groups > 1)
+        hipLaunchKernelGGL(k_smooth_u8_chain<true>, dim3(kBuffers * groups), dim3(sets * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else
-        hipLaunchKernelGGL(k_smooth_u8_chain, dim3(kBuffers), dim3(sets * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+        hipLaunchKernelGGL(k_smooth_u8_chain<false>, dim3(kBuffers), dim3(sets * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     return hipGetLastError();
 }
 

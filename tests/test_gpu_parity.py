@@ -505,6 +505,47 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
         assert np.array_equal(ora.pool(), flt.read_pool(0))
 
 
+# 8-bit chains over several workgroups per cost buffer (sn_policy.chain = 1, 2, 4, 8; k_smooth_u8_chain<true>): the hand-off
+# between two workgroups goes through memory and round counters -- every count must give the oracle's frames.
+GROUP_CASES = [
+    # fmt, w, h, kw, frames
+    ("YUV420P8", 720, 96, dict(aac=48), 12),     # two strips: 36 passes over sixteen slots, several cycles
+    ("YUV420P8", 720, 480, dict(aac=48), 7),     # the bench's history-carrying clip: 49 rounds a pass
+    ("Y8", 1000, 56, dict(aa=20), 23),           # three strips: two workgroups at most (pool_chain_groups), the rest of the counts fall back to that
+    ("Y8", 40, 200, dict(order=0), 40),          # one strip: thirty-two slots
+    ("YUV420P8", 1456, 40, dict(aac=10), 9),     # four strips
+    ("YUV444P8", 3000, 24, dict(aac=48), 5),     # seven strips: two workgroups at most
+]
+
+
+@pytest.mark.parametrize("fmt,w,h,kw,N", GROUP_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}" for c in GROUP_CASES])
+@pytest.mark.parametrize("groups", [1, 2, 4, 8])
+def test_chain_over_several_workgroups_per_buffer_matches_oracle(hip_lib, monkeypatch, fmt, w, h, kw, N, groups):
+    import torch
+    from avisynth_sangnom2_amd import capi
+    monkeypatch.setitem(capi.POLICY_DEFAULTS, "chain", groups)
+    clip = clip_format(fmt, w, h)
+    frames = make_frames(clip, "noise", N - 1, seed0=11) + [synth.frame(clip, "checker", seed=4)]
+    ora = Oracle(oracle_cfg(clip, **kw))
+    dev = torch.device("cuda:0")
+    with SangNom2(clip, max_batch=N, **kw) as flt:
+        assert not flt.info().history_free
+        assert flt.get_policy().chain == groups
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).to(dev) for p in range(clip.planes)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(clip.planes)]
+        torch.cuda.synchronize()
+        for rnd in range(2):  # the second launch starts from the pool the first one left
+            flt.process_batch(src, dst)
+            flt.synchronize()
+            for f in range(N):
+                want = ora.process(frames[f])
+                for p in range(clip.planes):
+                    got = dst[p][f].cpu().numpy()
+                    assert same(want[p], got), f"{groups} workgroups, round {rnd} frame {f} plane {p}: " + describe_diff(want[p], got)
+        assert flt.info().chained_frames == 2 * N
+        assert np.array_equal(ora.pool(), flt.read_pool(0))
+
+
 def test_host_ring_groups_of_a_history_carrying_clip_run_as_chains(hip_lib):
     """sn_submit_host / sn_collect_host with a ring deep enough for groups of several frames: a group's launch is a chain."""
     clip = clip_format("YUV420P8", 720, 64)
