@@ -37,7 +37,7 @@ def test_the_library_reads_no_environment_variable(hip_lib):
     assert "getenv" not in syms, "libsangnom_hip.so imports getenv"
     h = ctypes.c_void_p()
     cfg = _cfg()
-    for bad in (dict(small_launches=7), dict(chain=1), dict(copy_threads=99), dict(scratch_budget_mb=-1)):
+    for bad in (dict(small_launches=7), dict(chain=3), dict(chain=-2), dict(copy_threads=99), dict(scratch_budget_mb=-1)):
         pol = capi.SnPolicy(struct_size=ctypes.sizeof(capi.SnPolicy), **bad)
         assert hip_lib.sn_create_with_policy(ctypes.byref(cfg), ctypes.byref(pol), ctypes.byref(h)) == capi.SN_ERR_INVALID_ARG
         assert b"sn_policy" in hip_lib.sn_last_error(None)
