@@ -522,7 +522,7 @@ static const char* policy_text(const sn_policy* p)
     if (p->struct_size != (int32_t)sizeof(sn_policy)) return "sn_policy.struct_size mismatch";
     if (p->small_launches != SN_SMALL_AUTO && p->small_launches != SN_SMALL_SWEEP) return "sn_policy.small_launches must be SN_SMALL_AUTO or SN_SMALL_SWEEP";
     if (p->chain != 0 && p->chain != -1 && p->chain != 1 && p->chain != 2 && p->chain != 4 && p->chain != 8)
-        return "sn_policy.chain must be 0 (on), -1 (off), or 1, 2, 4, 8 (workgroups per buffer of an 8-bit chain)";
+        return "sn_policy.chain must be 0 (on), -1 (off), or 1, 2, 4, 8 (workgroups per cost buffer of a chain)";
     if (p->copy_threads < 0 || p->copy_threads > 16) return "sn_policy.copy_threads must be 0..16";
     if (p->scratch_budget_mb < 0) return "sn_policy.scratch_budget_mb must not be negative";
     return nullptr;
@@ -1081,7 +1081,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
 constexpr int SN_CHAIN_UNAVAILABLE = -1000;  // internal: run_chain could not get its ring, run_batch falls back
 constexpr size_t kChainFlagBytes = (size_t)sn::kBuffers * sn::kChainMaxGroups * 32 * sizeof(uint32_t);
 #ifndef SN_CHAIN_DEFAULT_GROUPS
-#define SN_CHAIN_DEFAULT_GROUPS 4
+#define SN_CHAIN_DEFAULT_GROUPS 8
 #endif
 constexpr int kChainDefaultGroups = SN_CHAIN_DEFAULT_GROUPS;  // sn_policy.chain = 0
 constexpr int kChainSlack = 2;  // rounds a workgroup's slots start later than lockstep with the workgroup before it would need
@@ -1123,7 +1123,7 @@ static int ensure_chain(Context* c, int pn, hipStream_t st)
     }
     SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
     c->chain_origin = 0;
-    if (c->cfg.bytes_per_sample == 1) {
+    {
         SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chain_flags), kChainFlagBytes));
         SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->chain_status), sizeof(uint32_t), hipHostMallocDefault));
         *c->chain_status = 0;

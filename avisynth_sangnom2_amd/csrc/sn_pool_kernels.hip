@@ -421,6 +421,79 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs po
     }
 }
 
+// ---- chains over several workgroups per buffer (see k_smooth_u8_chain): the pieces the three sample types share ----
+constexpr int kChainSpinLimit = 1 << 20;  // x (s_sleep 8 + a load from memory): two seconds and more
+
+// sixteen bytes of a pool row; COHERENT: as agent-scope relaxed atomics (global_load / global_store ... sc1), two of eight
+// bytes each -- a row is only ever read after the round counters said its writer is done with it
+template <bool COHERENT>
+__device__ __forceinline__ uint4 chain_load16(const void* p)
+{
+    if constexpr (COHERENT) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+template <bool COHERENT>
+__device__ __forceinline__ void chain_store16(void* p, uint4 v)
+{
+    if constexpr (COHERENT) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+        __hip_atomic_store(q, (unsigned long long)v.x | (unsigned long long)v.y << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, (unsigned long long)v.z | (unsigned long long)v.w << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+
+// The round counters of a buffer's workgroups.  enter(), right after the barrier that opens round `round`: the workgroup
+// publishes "rounds < round are complete" (the barrier waited for its stores), and the waves of its first slot make sure
+// the workgroup before it has completed round `round - 1 - slack` -- with the value they fetched while the round before
+// ran if that is enough (in step it is: the schedule starts a workgroup's slots `slack` rounds late), polling otherwise,
+// for two seconds at most: then the workgroup gives up waiting for good and raises the host-visible status word.
+struct ChainSync {
+    unsigned* mine;
+    const unsigned* his;
+    unsigned* status;
+    int slack;
+    unsigned seen;
+    bool gave_up;
+    __device__ __forceinline__ void init(const ChainArgs& ch, int b, int grp)
+    {
+        mine = ch.flags + (b * ch.groups + grp) * 32;  // a cache line of 128 bytes each
+        his = ch.flags + (b * ch.groups + (grp + ch.groups - 1) % ch.groups) * 32;
+        status = ch.status;
+        slack = ch.slack;
+        seen = 0;
+        gave_up = false;
+    }
+    __device__ __forceinline__ void enter(int round, bool first_slot, int tid)
+    {
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (tid == 0) __hip_atomic_store(mine, (unsigned)round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int need = round - slack;
+        if (first_slot && !gave_up) {
+            if (need > 0 && (int)seen < need) {
+                int spins = 0;
+                while ((int)(seen = __hip_atomic_load(his, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                    if (++spins > kChainSpinLimit) {
+                        gave_up = true;
+                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            seen = __hip_atomic_load(his, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next round
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    }
+};
+
 // History-carrying 8-bit clips (pool cells a pass does not write keep what the pass before it left): the
 // passes of a stream form a chain, but pass j + 1 only needs rows r + 1, r + 2 of what pass j smoothed, so one
 // persistent workgroup per buffer keeps `lanes` passes in flight, each on the nw waves of a strip set
@@ -445,7 +518,6 @@ constexpr int kChainLag = 3;
 #define SN_CHAIN8_THREADS 1024  // sixteen waves, four per SIMD: the two-pass body fits 128 registers (512 threads measured slower)
 #endif
 constexpr int kChain8Threads = SN_CHAIN8_THREADS;
-constexpr int kChainSpinLimit = 1 << 20;  // x (s_sleep 8 + a load from memory): two seconds and more
 
 // Round 3: SEVERAL workgroups per buffer (GROUPED).  One workgroup is bound by what its CU issues (profiles/r3_chain.md:
 // one VALU instruction per 4.7 cycles and SIMD where the instruction class's floor is 4.06), and a pass can only start
@@ -603,38 +675,11 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
         }
     };
 
-    unsigned* my_flag = nullptr;
-    const unsigned* his_flag = nullptr;
-    bool gave_up = false;
-    unsigned seen = 0;  // the round counter of the workgroup before this one, as last fetched
-    if constexpr (GROUPED) {
-        my_flag = ch.flags + (b * groups + grp) * 32;  // a cache line of 128 bytes each
-        his_flag = ch.flags + (b * groups + (grp + groups - 1) % groups) * 32;
-    }
+    ChainSync sync{};
+    if constexpr (GROUPED) sync.init(ch, b, grp);
     for (int round = 0; round < total; ++round) {
         __syncthreads();  // (waits for this wave's stores and loads, then for everybody's)
-        if constexpr (GROUPED) {
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            if (tid == 0) __hip_atomic_store(my_flag, (unsigned)round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // rounds < round are complete
-            const int need = round - slack;  // ... of the workgroup before this one: what this round fetches from it is there then
-            if (pair == 0 && !gave_up) {
-                // `seen` was fetched while the round before this one ran (a poll is a trip to memory: on the round's critical
-                // path it would cost more than the round's arithmetic); in step it is `slack` rounds ahead of what is needed
-                if (need > 0 && (int)seen < need) {
-                    int spins = 0;
-                    while ((int)(seen = __hip_atomic_load(his_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-                        if (++spins > kChainSpinLimit) {
-                            gave_up = true;
-                            __hip_atomic_store(ch.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                }
-                seen = __hip_atomic_load(his_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next round
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        }
+        if constexpr (GROUPED) sync.enter(round, pair == 0, tid);
         schedule(lo, 2 * pair, false, round);
         schedule(hi, 2 * pair + 1, true, round);
         if (!lo.run && !hi.run) {
@@ -734,7 +779,11 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
     }
 }
 
-// The chain for 9..16-bit samples: the same schedule around the row body of k_smooth_u16_strips.
+// The chain for 9..16-bit samples: the same schedule around the row body of k_smooth_u16_strips.  GROUPED: over several
+// workgroups per buffer as k_smooth_u8_chain<true> -- with one pass per wave a workgroup of sixteen waves only holds
+// 16 / nw passes, so here the workgroups ADD slots (up to the sixteen the lag of three rounds can use) before they
+// shorten the rounds.
+template <bool GROUPED>
 __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
                                                                     int cycle)
 {
@@ -742,7 +791,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
     extern __shared__ __align__(16) unsigned char smem[];
     const int se = pool.stride_e;
     const int nl = se >> 3;  // lanes that own columns
-    const int b = blockIdx.x;
+    const int groups = GROUPED ? ch.groups : 1, slack = GROUPED ? ch.slack : 0;
+    const int b = GROUPED ? (int)blockIdx.x / groups : (int)blockIdx.x, grp = GROUPED ? (int)blockIdx.x % groups : 0;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int ps = (tid >> 6) / nw, wave = (tid >> 6) % nw;  // which pass of the `lanes` in flight, which strip of it
@@ -778,8 +828,9 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
         return r;
     };
     const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
-    const int ncycles = (ch.npass + lanes - 1) / lanes;
-    const int total = (ncycles - 1) * cycle + (lanes - 1) * kChainLag + pass_rounds;
+    const int slots = lanes * groups;  // passes in flight per buffer
+    const int ncycles = (ch.npass + slots - 1) / slots;
+    const int total = (ncycles - 1) * cycle + (slots - 1) * kChainLag + (groups - 1) * slack + pass_rounds;
 
     // state of the pass this wave is working on
     const uint16_t* own = nullptr;   // this lane's columns in the pass's slot ...
@@ -792,14 +843,18 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
     auto load = [&](int row) {
         row = row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
         const uint16_t* from = row >= 1 && row <= fresh_rows ? own : before;
-        return *reinterpret_cast<const uint4*>(from + (size_t)row * se);
+        return chain_load16<GROUPED>(from + (size_t)row * se);
     };
 
+    ChainSync sync{};
+    if constexpr (GROUPED) sync.init(ch, b, grp);
+    const int gslot = grp * lanes + ps;  // the slot among all of the buffer's
     for (int round = 0; round < total; ++round) {
         __syncthreads();
-        const int rel = round - ps * kChainLag;
+        if constexpr (GROUPED) sync.enter(round, ps == 0, tid);
+        const int rel = round - (gslot * kChainLag + grp * slack);
         if (rel < 0) continue;
-        const int j = (rel / cycle) * lanes + ps, t = rel % cycle - 1;
+        const int j = (rel / cycle) * slots + gslot, t = rel % cycle - 1;
         if (j >= ch.npass || t >= pass_rounds - 1) continue;
         if (t < 0) {  // the pass's first rows
             const int k = j % ch.pn;
@@ -848,7 +903,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
                     q.y = o.v[2] | (o.v[3] << 16);
                     q.z = o.v[4] | (o.v[5] << 16);
                     q.w = o.v[6] | (o.v[7] << 16);
-                    *reinterpret_cast<uint4*>(out + (size_t)r * se) = q;
+                    chain_store16<GROUPED>(out + (size_t)r * se, q);
                 }
                 prev = o;
                 cur = nxt;
@@ -865,6 +920,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
 
 // The chain for float samples: the same schedule around the row body of k_smooth_f32_strips (every sum in the
 // reference's order).
+template <bool GROUPED>
 __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
                                                                     int cycle)
 {
@@ -872,7 +928,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
     extern __shared__ __align__(16) unsigned char smem[];
     const int se = pool.stride_e;
     const int nl = se >> 3;  // lanes that own columns
-    const int b = blockIdx.x;
+    const int groups = GROUPED ? ch.groups : 1, slack = GROUPED ? ch.slack : 0;
+    const int b = GROUPED ? (int)blockIdx.x / groups : (int)blockIdx.x, grp = GROUPED ? (int)blockIdx.x % groups : 0;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int ps = (tid >> 6) / nw, wave = (tid >> 6) % nw;  // which pass of the `lanes` in flight, which strip of it
@@ -912,8 +969,9 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
         return __uint_as_float((mask & __float_as_uint(edge)) | (~mask & __float_as_uint(other)));
     };
     const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
-    const int ncycles = (ch.npass + lanes - 1) / lanes;
-    const int total = (ncycles - 1) * cycle + (lanes - 1) * kChainLag + pass_rounds;
+    const int slots = lanes * groups;  // passes in flight per buffer
+    const int ncycles = (ch.npass + slots - 1) / slots;
+    const int total = (ncycles - 1) * cycle + (slots - 1) * kChainLag + (groups - 1) * slack + pass_rounds;
 
     // state of the pass this wave is working on
     const float* own = nullptr;   // this lane's columns in the pass's slot ...
@@ -927,16 +985,21 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
         row = row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
         const float4* from = reinterpret_cast<const float4*>((row >= 1 && row <= fresh_rows ? own : before) + (size_t)row * se);
         Raw q;
-        q.lo = from[0];
-        q.hi = from[1];
+        const uint4 a = chain_load16<GROUPED>(from), c = chain_load16<GROUPED>(from + 1);
+        q.lo = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        q.hi = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
         return q;
     };
 
+    ChainSync sync{};
+    if constexpr (GROUPED) sync.init(ch, b, grp);
+    const int gslot = grp * lanes + ps;  // the slot among all of the buffer's
     for (int round = 0; round < total; ++round) {
         __syncthreads();
-        const int rel = round - ps * kChainLag;
+        if constexpr (GROUPED) sync.enter(round, ps == 0, tid);
+        const int rel = round - (gslot * kChainLag + grp * slack);
         if (rel < 0) continue;
-        const int j = (rel / cycle) * lanes + ps, t = rel % cycle - 1;
+        const int j = (rel / cycle) * slots + gslot, t = rel % cycle - 1;
         if (j >= ch.npass || t >= pass_rounds - 1) continue;
         if (t < 0) {  // the pass's first rows
             const int k = j % ch.pn;
@@ -978,8 +1041,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
                     o.v[m] = ((((((X[m] + X[m + 1]) + X[m + 2]) + X[m + 3]) + X[m + 4]) + X[m + 5]) + X[m + 6]) * 0.0625f;
                 if (real) {
                     float4* q = reinterpret_cast<float4*>(out + (size_t)r * se);
-                    q[0] = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
-                    q[1] = make_float4(o.v[4], o.v[5], o.v[6], o.v[7]);
+                    chain_store16<GROUPED>(q, make_uint4(__float_as_uint(o.v[0]), __float_as_uint(o.v[1]), __float_as_uint(o.v[2]), __float_as_uint(o.v[3])));
+                    chain_store16<GROUPED>(q + 1, make_uint4(__float_as_uint(o.v[4]), __float_as_uint(o.v[5]), __float_as_uint(o.v[6]), __float_as_uint(o.v[7])));
                 }
                 prev = o;
                 cur = nxt;
@@ -1632,14 +1695,24 @@ hipError_t launch_pool_finalize(hipStream_t st, const PlaneArgs& p, const PoolAr
     return hipErrorInvalidValue;
 }
 
-// 8-bit chains: workgroups per buffer.  Each gets 1 / groups of the sixteen waves; a workgroup needs at least one pair of
-// passes (nw waves).
+// Workgroups per buffer a chain can be spread over (`want` or fewer).  8-bit: each gets 1 / groups of the sixteen waves
+// and needs at least one pair of passes (nw waves).  16-bit and float (one pass per wave): thirty-two waves in all, sixteen
+// per workgroup at most, and a workgroup needs a pass (nw waves).
+static int chain_waves(int bytes, int groups)
+{
+    const int all = bytes == 1 ? kChain8Threads / 64 : 2 * (kSmoothThreads / 64);
+    const int w = all / groups;
+    return w > kSmoothThreads / 64 ? kSmoothThreads / 64 : w;
+}
 int pool_chain_groups(int bytes, int stride_e, int want)
 {
-    if (bytes != 1 || want <= 1) return 1;
+    if (want <= 1) return 1;
     const int nw = v3c::strips_for(stride_e / 8);
     int g = 1;
-    while (g * 2 <= want && g * 2 <= kChainMaxGroups && kChain8Threads / 64 / (g * 2) >= nw) g *= 2;
+    while (g * 2 <= want && g * 2 <= kChainMaxGroups && chain_waves(bytes, g * 2) >= nw) g *= 2;
+    // float rows are four coherent loads and four stores of eight bytes: with sixteen waves in each of two workgroups that
+    // costs more than the second workgroup's slots bring (720x480 YUV420PS: 7.8 k frames/s -> 6.1 k; 10.4 k with four, 15.2 k with eight)
+    if (bytes == 4 && g == 2) g = 1;
     return g;
 }
 
@@ -1652,23 +1725,27 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
         if (chain.w[k] % 8 != 0 || chain.nr[k] >= pool.bh) return hipErrorInvalidValue;
     const int nw = v3c::strips_for(pool.stride_e / 8);
     if (groups > 1) {
-        if (bytes != 1 || groups != pool_chain_groups(bytes, pool.stride_e, groups) || !chain.flags || !chain.status || chain.slack < 0)
-            return hipErrorInvalidValue;
-        lanes = 2 * (kChain8Threads / 64 / groups / nw);  // per workgroup: two passes per set of nw waves
+        if (groups != pool_chain_groups(bytes, pool.stride_e, groups) || !chain.flags || !chain.status || chain.slack < 0) return hipErrorInvalidValue;
+        lanes = (bytes == 1 ? 2 : 1) * (chain_waves(bytes, groups) / nw);  // per workgroup (8-bit: two passes per set of nw waves)
     }
     const int pass_rounds = 1 + (pool.bh - 1 + v3c::K - 1) / v3c::K;
     const int busy = lanes * groups * kChainLag + groups * (groups > 1 ? chain.slack : 0);  // rounds until a slot may take its next pass
     const int cycle = pass_rounds > busy ? pass_rounds : busy;
     const int sets = bytes == 1 ? lanes / 2 : lanes;  // sets of nw waves (8-bit: a set carries two passes)
     const size_t lds = (size_t)sets * 2 * nw * 2 * v3c::GH * 8 * sizeof(unsigned);
-    if (bytes == 4)
-        hipLaunchKernelGGL(k_smooth_f32_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+    const dim3 grid(kBuffers * groups), block(sets * nw * 64);
+    if (bytes == 4 && groups > 1)
+        hipLaunchKernelGGL(k_smooth_f32_chain<true>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+    else if (bytes == 4)
+        hipLaunchKernelGGL(k_smooth_f32_chain<false>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+    else if (bytes == 2 && groups > 1)
+        hipLaunchKernelGGL(k_smooth_u16_chain<true>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else if (bytes == 2)
-        hipLaunchKernelGGL(k_smooth_u16_chain, dim3(kBuffers), dim3(lanes * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+        hipLaunchKernelGGL(k_smooth_u16_chain<false>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else if (groups > 1)
-        hipLaunchKernelGGL(k_smooth_u8_chain<true>, dim3(kBuffers * groups), dim3(sets * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+        hipLaunchKernelGGL(k_smooth_u8_chain<true>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else
-        hipLaunchKernelGGL(k_smooth_u8_chain<false>, dim3(kBuffers), dim3(sets * nw * 64), lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+        hipLaunchKernelGGL(k_smooth_u8_chain<false>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     return hipGetLastError();
 }
 

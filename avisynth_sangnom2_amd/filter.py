@@ -84,7 +84,7 @@ class SangNom2:
         self.device = device
         self._h = ctypes.c_void_p()
         # scheduling only (sn_policy, sangnom_hip.h); None = capi.POLICY_DEFAULTS.  chain: 0 on, -1 off, 1 / 2 / 4 / 8 = on with
-        # that many workgroups per cost buffer for 8-bit clips
+        # at most that many workgroups per cost buffer
         pol = capi.policy(small_launches=small_launches, chain=chain, copy_threads=copy_threads, scratch_budget_mb=scratch_budget_mb)
         rc = self._lib.sn_create_with_policy(ctypes.byref(cfg), ctypes.byref(pol), ctypes.byref(self._h))
         if rc != capi.SN_OK:

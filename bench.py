@@ -39,6 +39,8 @@ WORKLOADS = {
     "2160p-YUV420P8-isolated": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48, isolated_planes=True)),
     "480p-YUV420P8": ("YUV420P8", 720, 480, dict(order=1, aa=48, aac=48)),  # width % 32 != 0: history-carrying
     "480p-YUV420P8-fresh": ("YUV420P8", 720, 480, dict(order=1, aa=48, aac=48, fresh_pool=True)),
+    "480p-YUV420P16": ("YUV420P16", 720, 480, dict(order=1, aa=48, aac=48)),  # the 16-bit and float chains
+    "480p-YUV420PS": ("YUV420PS", 720, 480, dict(order=1, aa=48, aac=48)),
     "2160p-turned-Y8-fresh": ("Y8", 2160, 3840, dict(order=1, aa=48, fresh_pool=True)),
     "2160p-Y16": ("Y16", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420P16": ("YUV420P16", 3840, 2160, dict(order=1, aa=48, aac=48)),

@@ -104,8 +104,8 @@ typedef struct sn_policy {
     int32_t struct_size;        /* = sizeof(sn_policy)                                                             */
     int32_t small_launches;     /* SN_SMALL_*                                                                      */
     int32_t chain;              /* history-carrying clips as chains of passes: 0 = on, -1 = off;  *
-                                 * 1, 2, 4, 8 = on, with that many workgroups (CUs) per cost buffer for 8-bit clips *
-                                 * (0 picks 4; 1 is the single-workgroup chain of round 2)                          */
+                                 * 1, 2, 4, 8 = on, with at most that many workgroups (CUs) per cost buffer (0 picks *
+                                 * 8; wide pool rows allow fewer; 1 is the single-workgroup chain of round 2)       */
     int32_t copy_threads;       /* host threads that stage / copy lines, the caller included; 0 = by core count,   *
                                  * at most 16.  Takes effect when the context first needs them                      */
     int32_t scratch_budget_mb;  /* device scratch per kind (pool slots; hand-off pools of the coupled sweeps; the    *

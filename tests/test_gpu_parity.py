@@ -505,7 +505,7 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
         assert np.array_equal(ora.pool(), flt.read_pool(0))
 
 
-# 8-bit chains over several workgroups per cost buffer (sn_policy.chain = 1, 2, 4, 8; k_smooth_u8_chain<true>): the hand-off
+# Chains over several workgroups per cost buffer (sn_policy.chain = 1, 2, 4, 8; k_smooth_{u8,u16,f32}_chain<true>): the hand-off
 # between two workgroups goes through memory and round counters -- every count must give the oracle's frames.
 GROUP_CASES = [
     # fmt, w, h, kw, frames
@@ -515,6 +515,12 @@ GROUP_CASES = [
     ("Y8", 40, 200, dict(order=0), 40),          # one strip: thirty-two slots
     ("YUV420P8", 1456, 40, dict(aac=10), 9),     # four strips
     ("YUV444P8", 3000, 24, dict(aac=48), 5),     # seven strips: two workgroups at most
+    ("YUV420P10", 720, 96, dict(aac=48), 12),    # 9..16-bit samples (k_smooth_u16_chain<true>): the workgroups add slots
+    ("Y16", 1000, 56, dict(aa=20), 23),
+    ("Y12", 40, 200, dict(order=0), 40),
+    ("YUV420PS", 720, 96, dict(aac=48), 12),     # float samples (k_smooth_f32_chain<true>)
+    ("Y32", 1000, 56, dict(aa=20), 23),
+    ("YUV444PS", 3000, 24, dict(aac=48), 5),
 ]
 
 
@@ -531,8 +537,9 @@ def test_chain_over_several_workgroups_per_buffer_matches_oracle(hip_lib, monkey
     with SangNom2(clip, max_batch=N, **kw) as flt:
         assert not flt.info().history_free
         assert flt.get_policy().chain == groups
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).to(dev) for p in range(clip.planes)]
-        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(clip.planes)]
+        view = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).to(dev) for p in range(clip.planes)]
+        dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
         for rnd in range(2):  # the second launch starts from the pool the first one left
             flt.process_batch(src, dst)
@@ -540,7 +547,7 @@ def test_chain_over_several_workgroups_per_buffer_matches_oracle(hip_lib, monkey
             for f in range(N):
                 want = ora.process(frames[f])
                 for p in range(clip.planes):
-                    got = dst[p][f].cpu().numpy()
+                    got = dst[p][f].cpu().numpy().view(clip.dtype)
                     assert same(want[p], got), f"{groups} workgroups, round {rnd} frame {f} plane {p}: " + describe_diff(want[p], got)
         assert flt.info().chained_frames == 2 * N
         assert np.array_equal(ora.pool(), flt.read_pool(0))

@@ -2,7 +2,7 @@
 # tools/chain_prof.sh <lib.so> <tag>: kernel durations and SQ counters of the 480p history-carrying stream with one build
 set -e
 lib=avisynth_sangnom2_amd/libsangnom_hip.so
-cp "$1" $lib
+[ "$1" -ef $lib ] || cp "$1" $lib
 out=gpurun_out/chain_$2
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
