@@ -594,8 +594,8 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
     };
     const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
     const int slots = lanes * groups;  // passes in flight per buffer; slot g starts (g * kChainLag + its workgroup * slack) rounds in
-    const int ncycles = (ch.npass + slots - 1) / slots;
-    const int total = (ncycles - 1) * cycle + (slots - 1) * kChainLag + (groups - 1) * slack + pass_rounds;
+    const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
+    const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
 
     // state of the two passes this wave is working on (lo: low halves, pass slot 2 * pair; hi: high halves)
     struct Half {
@@ -829,8 +829,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
     };
     const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
     const int slots = lanes * groups;  // passes in flight per buffer
-    const int ncycles = (ch.npass + slots - 1) / slots;
-    const int total = (ncycles - 1) * cycle + (slots - 1) * kChainLag + (groups - 1) * slack + pass_rounds;
+    const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
+    const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
 
     // state of the pass this wave is working on
     const uint16_t* own = nullptr;   // this lane's columns in the pass's slot ...
@@ -970,8 +970,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
     };
     const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
     const int slots = lanes * groups;  // passes in flight per buffer
-    const int ncycles = (ch.npass + slots - 1) / slots;
-    const int total = (ncycles - 1) * cycle + (slots - 1) * kChainLag + (groups - 1) * slack + pass_rounds;
+    const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
+    const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
 
     // state of the pass this wave is working on
     const float* own = nullptr;   // this lane's columns in the pass's slot ...
