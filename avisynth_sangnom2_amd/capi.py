@@ -26,6 +26,7 @@ EXPORTS = (
     "sn_aa_create", "sn_aa_process_host", "sn_aa_last_error", "sn_aa_destroy",
     "sn_pin_host_buffer", "sn_unpin_host_buffer", "sn_submit_host_to", "sn_debug_set_bands",
     "sn_create_with_policy", "sn_get_policy", "sn_set_policy", "sn_aa_create_with_policy",
+    "sn_debug_raise_chain_fault",
 )
 
 SN_SMALL_AUTO, SN_SMALL_SWEEP = 0, 1
@@ -130,6 +131,7 @@ def load():
     L.sn_debug_read_pool.argtypes = [vp, i32, vp, ctypes.c_size_t]
     L.sn_debug_read_coupled_rows.argtypes = [vp, i32, vp, ctypes.c_size_t]
     L.sn_debug_set_bands.argtypes = [vp, i32, i32]
+    L.sn_debug_raise_chain_fault.argtypes = [vp]
     L.sn_pin_host_buffer.argtypes = [vp, ctypes.c_size_t]
     L.sn_unpin_host_buffer.argtypes = [vp]
     L.sn_submit_host_to.argtypes = [vp, p3v, p3i, p3v, p3i, i32, ctypes.POINTER(i32)]

@@ -1799,6 +1799,15 @@ int sn_set_policy(sn_context* h, const sn_policy* policy)
     return SN_OK;
 }
 
+int sn_debug_raise_chain_fault(sn_context* h)
+{
+    Context* c = reinterpret_cast<Context*>(h);
+    if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
+    if (!c->chain_status) return sn::fail(c, SN_ERR_UNSUPPORTED, "sn_debug_raise_chain_fault: this context has not run a chain");
+    __atomic_store_n(c->chain_status, 1u, __ATOMIC_RELAXED);
+    return SN_OK;
+}
+
 int sn_debug_set_bands(sn_context* h, int32_t bands, int32_t warm_rows)
 {
     Context* c = reinterpret_cast<Context*>(h);

@@ -155,6 +155,10 @@ class SangNom2:
         self._check(self._lib.sn_get_policy(self._h, ctypes.byref(cur)))
         return cur
 
+    def raise_chain_fault(self) -> None:
+        """Test hook: as if a chain over several workgroups had timed out (sn_debug_raise_chain_fault)."""
+        self._check(self._lib.sn_debug_raise_chain_fault(self._h))
+
     def set_bands(self, bands: int = 0, warm_rows: int = 0) -> None:
         """Test hook: row bands of the small-launch path (sn_debug_set_bands)."""
         self._check(self._lib.sn_debug_set_bands(self._h, bands, warm_rows))

@@ -259,6 +259,12 @@ int sn_debug_read_coupled_rows(sn_context* ctx, int32_t which, void* host_dst, s
  * turns the bands off; warm_rows = 0 restores the default run-up.  A run-up of 1 makes nearly every frame fail. */
 int sn_debug_set_bands(sn_context* ctx, int32_t bands, int32_t warm_rows);
 
+/* Test hook for the chains over several workgroups per cost buffer (sn_policy.chain): raises the word a workgroup
+ * raises when it gives up waiting for the workgroup before it, as if the last chain had timed out.  Every later call
+ * that queues work or waits for the device then fails with SN_ERR_HIP; the context has to be recreated.
+ * SN_ERR_UNSUPPORTED if the context has not run a chain yet (the word lives with the chain's ring). */
+int sn_debug_raise_chain_fault(sn_context* ctx);
+
 int sn_abi_version(void);
 
 #ifdef __cplusplus

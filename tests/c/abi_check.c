@@ -17,7 +17,7 @@ int main(void)
                          (fn_t)sn_debug_read_coupled_rows, (fn_t)sn_debug_set_bands, (fn_t)sn_aa_create, (fn_t)sn_aa_process_host,
                          (fn_t)sn_aa_last_error, (fn_t)sn_aa_destroy, (fn_t)sn_pin_host_buffer, (fn_t)sn_unpin_host_buffer,
                          (fn_t)sn_submit_host_to, (fn_t)sn_create_with_policy, (fn_t)sn_get_policy, (fn_t)sn_set_policy,
-                         (fn_t)sn_aa_create_with_policy};
+                         (fn_t)sn_aa_create_with_policy, (fn_t)sn_debug_raise_chain_fault};
     sn_config c;
     char msg[256];
     size_t i;

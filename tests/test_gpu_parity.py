@@ -576,6 +576,39 @@ def test_host_ring_groups_of_a_history_carrying_clip_run_as_chains(hip_lib):
             assert same(want[p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[p], got[f][p])
 
 
+def test_a_chain_that_timed_out_fails_every_later_call(hip_lib):
+    """A workgroup that gives up waiting for the one before it raises a host-visible word (k_smooth_*_chain<true>); from
+    then on the context refuses to queue work and reports the fault wherever it waits for the device."""
+    import torch
+    from avisynth_sangnom2_amd.filter import SangNomError
+    clip = clip_format("Y8", 1000, 56)
+    frames = make_frames(clip, "noise", 12, seed0=5)
+    dev = torch.device("cuda:0")
+    with SangNom2(clip, max_batch=12) as flt:
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).to(dev)]
+        dst = [torch.zeros((12,) + flt.plane_shape_out(0), dtype=torch.uint8, device=dev)]
+        torch.cuda.synchronize()
+        flt.process_batch(src, dst)
+        flt.synchronize()
+        assert flt.info().chained_frames == 12
+        flt.raise_chain_fault()
+        with pytest.raises(SangNomError, match="timed out between two workgroups") as e:
+            flt.synchronize()
+        assert e.value.code == capi_code("SN_ERR_HIP")
+        with pytest.raises(SangNomError, match="timed out between two workgroups"):
+            flt.process_batch(src, dst)
+        with pytest.raises(SangNomError, match="timed out between two workgroups"):
+            flt.get_frame(frames[0])
+    with SangNom2(clip) as flt:  # no chain yet: nothing to raise
+        with pytest.raises(SangNomError, match="has not run a chain"):
+            flt.raise_chain_fault()
+
+
+def capi_code(name):
+    from avisynth_sangnom2_amd import capi
+    return getattr(capi, name)
+
+
 def test_chain_can_be_switched_off(hip_lib, monkeypatch):
     import torch
     from avisynth_sangnom2_amd import capi
