@@ -51,6 +51,9 @@ struct ChainArgs {
     int32_t groups, slack;  // 8-bit: workgroups per buffer (<= 1: one) and the rounds of slack between two of them
     uint32_t* flags;        // groups > 1: kBuffers * kChainMaxGroups * 32 words, zero at launch (rounds completed per workgroup)
     uint32_t* status;       // groups > 1: host-visible word, set when a workgroup stopped waiting for the one before it
+    int32_t rows;           // > 0: stage 2 stops there (rows 1 .. rows - 1 are smoothed), as PoolArgs::rows
+    int32_t nchains, chain_step;  // nchains > 1: that many independent chains of npass passes (blockIdx.y), chain y starting at
+                                  // slot origin + y * chain_step (> npass; no wrap around the ring; one workgroup per buffer)
 };
 
 struct Context;

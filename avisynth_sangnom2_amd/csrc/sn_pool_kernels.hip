@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    T* buf = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    T* buf = reinterpret_cast<T*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     // the workgroup has ceil(se / NC) threads rounded up to whole waves; the idle lanes of the last wave compute on
     // column 0's data and store nothing, so every thread reaches every barrier
     const bool active = (int)threadIdx.x * NC < se;
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, i
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    uint8_t* buf = pool.base + (int64_t)(slot0 + f) * pool.slot_bytes + (size_t)b * bufsz;
+    uint8_t* buf = pool.base + slot_of(pool, slot0, f) * pool.slot_bytes + (size_t)b * bufsz;
     const int tid = threadIdx.x;
     const bool active = tid < nt;
     const int t = active ? tid : 0;  // idle lanes of the last wave shadow thread 0 and store nothing
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs po
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    uint8_t* buf = pool.base + (int64_t)(slot0 + f) * pool.slot_bytes + (size_t)b * bufsz;
+    uint8_t* buf = pool.base + slot_of(pool, slot0, f) * pool.slot_bytes + (size_t)b * bufsz;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int gl;
     bool ghost;
@@ -592,7 +592,8 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
         }
         return r;
     };
-    const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int rows = ch.rows > 0 && ch.rows < pool.bh ? ch.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int origin = ch.origin + (int)blockIdx.y * ch.chain_step;           // blockIdx.y: one of several independent chains
     const int slots = lanes * groups;  // passes in flight per buffer; slot g starts (g * kChainLag + its workgroup * slack) rounds in
     const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
     const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
@@ -656,7 +657,7 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
         H.fetch = active && H.t < 0;
         if (H.fetch) {
             const int k = j % ch.pn;
-            const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
+            const int64_t s_own = (origin + 1 + j) % pool.slot_mod, s_before = (origin + j) % pool.slot_mod;
             H.own = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
             H.before = pool.base + s_before * pool.slot_bytes + (size_t)b * bufsz + x0;
             H.out = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
@@ -827,7 +828,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
         r.v[6] = q.w & 0xffffu; r.v[7] = q.w >> 16;
         return r;
     };
-    const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int rows = ch.rows > 0 && ch.rows < pool.bh ? ch.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int origin = ch.origin + (int)blockIdx.y * ch.chain_step;           // blockIdx.y: one of several independent chains
     const int slots = lanes * groups;  // passes in flight per buffer
     const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
     const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
@@ -858,7 +860,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
         if (j >= ch.npass || t >= pass_rounds - 1) continue;
         if (t < 0) {  // the pass's first rows
             const int k = j % ch.pn;
-            const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
+            const int64_t s_own = (origin + 1 + j) % pool.slot_mod, s_before = (origin + j) % pool.slot_mod;
             own = reinterpret_cast<const uint16_t*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
             before = reinterpret_cast<const uint16_t*>(pool.base + s_before * pool.slot_bytes) + (size_t)b * bufsz + x0;
             out = reinterpret_cast<uint16_t*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
@@ -968,7 +970,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
     auto pick = [](unsigned mask, float edge, float other) {  // bitwise, as in k_smooth_u8_strips
         return __uint_as_float((mask & __float_as_uint(edge)) | (~mask & __float_as_uint(other)));
     };
-    const int rows = pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int rows = ch.rows > 0 && ch.rows < pool.bh ? ch.rows : pool.bh;  // rows 1 .. rows - 1 are smoothed
+    const int origin = ch.origin + (int)blockIdx.y * ch.chain_step;           // blockIdx.y: one of several independent chains
     const int slots = lanes * groups;  // passes in flight per buffer
     const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
     const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
@@ -1003,7 +1006,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
         if (j >= ch.npass || t >= pass_rounds - 1) continue;
         if (t < 0) {  // the pass's first rows
             const int k = j % ch.pn;
-            const int64_t s_own = (ch.origin + 1 + j) % pool.slot_mod, s_before = (ch.origin + j) % pool.slot_mod;
+            const int64_t s_own = (origin + 1 + j) % pool.slot_mod, s_before = (origin + j) % pool.slot_mod;
             own = reinterpret_cast<const float*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
             before = reinterpret_cast<const float*>(pool.base + s_before * pool.slot_bytes) + (size_t)b * bufsz + x0;
             out = reinterpret_cast<float*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
@@ -1072,7 +1075,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, 
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x;
     const bool active = tid < nt;
     const int t = active ? tid : 0;  // idle lanes of the last wave shadow thread 0 and store nothing
@@ -1158,7 +1161,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_strips(PoolArgs p
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int gl;
     bool ghost;
@@ -1270,7 +1273,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32x8(PoolArgs pool, 
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    float* buf = reinterpret_cast<float*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    float* buf = reinterpret_cast<float*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x;
     const bool active = tid < nt;
     const int t = active ? tid : 0;  // idle lanes of the last wave shadow thread 0 and store nothing
@@ -1360,7 +1363,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_strips(PoolArgs p
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    float* buf = reinterpret_cast<float*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    float* buf = reinterpret_cast<float*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int gl;
     bool ghost;
@@ -1474,7 +1477,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_strided(PoolArgs pool
     const int f = blockIdx.y;
     if (pool.guard && pool.guard[f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
-    T* buf = reinterpret_cast<T*>(pool.base + (int64_t)(slot0 + f) * pool.slot_bytes) + (size_t)b * bufsz;
+    T* buf = reinterpret_cast<T*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x;
 
     W prev[NC], cur[NC], nxt[NC];
@@ -1720,7 +1723,11 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
 {
     const int groups = chain.groups > 1 ? chain.groups : 1;
     int lanes = pool_chain_lanes(bytes, pool.stride_e);
-    if (lanes < 2 || pool.slot_mod <= chain.npass || chain.npass < 1 || pool.bh < 2) return hipErrorInvalidValue;
+    const int nchains = chain.nchains > 1 ? chain.nchains : 1;
+    if (lanes < 2 || chain.npass < 1 || pool.bh < 2) return hipErrorInvalidValue;
+    if (nchains == 1 ? pool.slot_mod <= chain.npass
+                     : (groups > 1 || chain.chain_step <= chain.npass || chain.origin + (int64_t)nchains * chain.chain_step > pool.slot_mod))
+        return hipErrorInvalidValue;  // (several chains: each has its slots to itself, none wraps around the ring, one workgroup per buffer)
     for (int k = 0; k < chain.pn; ++k)
         if (chain.w[k] % 8 != 0 || chain.nr[k] >= pool.bh) return hipErrorInvalidValue;
     const int nw = v3c::strips_for(pool.stride_e / 8);
@@ -1728,12 +1735,13 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
         if (groups != pool_chain_groups(bytes, pool.stride_e, groups) || !chain.flags || !chain.status || chain.slack < 0) return hipErrorInvalidValue;
         lanes = (bytes == 1 ? 2 : 1) * (chain_waves(bytes, groups) / nw);  // per workgroup (8-bit: two passes per set of nw waves)
     }
-    const int pass_rounds = 1 + (pool.bh - 1 + v3c::K - 1) / v3c::K;
+    const int rows = chain.rows > 0 && chain.rows < pool.bh ? chain.rows : pool.bh;
+    const int pass_rounds = 1 + (rows - 1 + v3c::K - 1) / v3c::K;
     const int busy = lanes * groups * kChainLag + groups * (groups > 1 ? chain.slack : 0);  // rounds until a slot may take its next pass
     const int cycle = pass_rounds > busy ? pass_rounds : busy;
     const int sets = bytes == 1 ? lanes / 2 : lanes;  // sets of nw waves (8-bit: a set carries two passes)
     const size_t lds = (size_t)sets * 2 * nw * 2 * v3c::GH * 8 * sizeof(unsigned);
-    const dim3 grid(kBuffers * groups), block(sets * nw * 64);
+    const dim3 grid(kBuffers * groups, nchains), block(sets * nw * 64);
     if (bytes == 4 && groups > 1)
         hipLaunchKernelGGL(k_smooth_f32_chain<true>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else if (bytes == 4)

@@ -1324,7 +1324,10 @@ def test_row_bands_serve_isolated_planes(hip_lib, monkeypatch, fmt, w, h, kw):
 
 
 @pytest.mark.parametrize("fmt,w,h,kw,n", [("Y8", 512, 300, {}, 5), ("Y8", 64, 200, dict(order=0), 7), ("Y16", 1056, 240, dict(aa=20), 3),
-                                          ("YUV444PS", 256, 200, dict(aac=48), 4), ("YUV420P8", 512, 320, dict(aac=48), 6)])
+                                          ("YUV444PS", 256, 200, dict(aac=48), 4), ("YUV420P8", 512, 320, dict(aac=48), 6),
+                                          # 4:2:0: luma in bands, U and V as one chain of two passes per frame (run_group)
+                                          ("YUV420P16", 512, 320, dict(aac=48), 4), ("YUV420PS", 256, 200, dict(aac=48), 3),
+                                          ("YUV420P8", 1024, 128, dict(aac=20, order=0), 5)])
 def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, h, kw, n):
     """A launch of a few frames (a host ring group, a short device batch) is cut into bands as well: frames x bands
     workgroups, one flag per frame.  One of the frames is a checkerboard, which may fail its check on its own."""
