@@ -543,8 +543,23 @@ constexpr int kChain8Threads = SN_CHAIN8_THREADS;
 // 720x480 YUV420P8, 512 frames per launch: 23.1 k frames/s with one workgroup per buffer, 28.4 k with two, 31.5 k with
 // four (the default: 36 CUs), 32.9 k with eight.  Tried and dropped: fetching a round's rows all at its start into a
 // second ring (slower), waiting only for the stores of a round's first two rows at the barrier (no change).
-template <bool GROUPED>
-__global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads) k_smooth_u8_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
+#ifdef SN_CHAIN_TIMING
+// -DSN_CHAIN_TIMING (tools/chain_timing.py): shader-clock cycles the waves that had rows spent, summed over them, in
+// [0] the barrier, [1] the hand-off wait, [2] the schedule and ghost refresh, [3] the rows, [4] the publish; [5] = wave-rounds counted
+__device__ unsigned long long sn_chain_cycles[6];
+#define SN_TICK(k)                                                     \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        acc_[k] += now_ - last_;                                       \
+        last_ = now_;                                                  \
+    } while (0)
+#else
+#define SN_TICK(k) do { } while (0)
+#endif
+// THREADS: the launch bound.  The workgroups of a spread chain and short chains (a frame's two or three passes) have eight
+// waves at most and 256 registers each; a long chain on one workgroup per buffer has sixteen waves and 128.
+template <bool GROUPED, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, ChainArgs ch, int nw, int lanes, int pass_rounds,
                                                                     int cycle)
 {
     using namespace v3c;
@@ -606,12 +621,13 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
         int fresh_rows;         // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
         int t;                  // block of K rows the pass is at in this round
         bool run, fetch;        // the pass has rows in this round / is in its first round
+        int phase, turn;        // the slot's clock: rounds since it last took a pass (< 0: not started yet), passes taken so far
         uint2 ring[K];          // rows fetched ahead
         uint2 first[3];         // GROUPED: rows 0 .. 2, from the pass's first round's start to its end
     };
     constexpr int kAhead = K;
     const uint8_t* idle = pool.base + (size_t)b * bufsz + x0;  // somewhere mapped for the loads of a half without a pass
-    Half lo{idle, idle, nullptr, 0, 0, false, false, {}, {}}, hi{idle, idle, nullptr, 0, 0, false, false, {}, {}};
+    Half lo{idle, idle, nullptr, 0, 0, false, false, 0, 0, {}, {}}, hi{idle, idle, nullptr, 0, 0, false, false, 0, 0, {}, {}};
     Row prev{}, cur{}, nxt{};
     auto load = [&](const Half& H, int row) {
         row = row < 0 ? 0 : row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
@@ -647,11 +663,22 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
     // where a pass slot stands in this round; fetches the pass's first rows (one workgroup per buffer: into its half of
     // the registers at once.  GROUPED: the loads come from memory, not from the L2, and a wave that sat through them would
     // hold up its workgroup at the next barrier and the workgroups behind it: they are taken in when the round is over)
+    // (The slot's clock is kept by counting: phase = rel % cycle and turn = rel / cycle for rel = round - the slot's start.
+    // Dividing every round cost a quarter of a round's cycles in scalar instructions, profiles/r3_chain.md.)
+    auto start_clock = [&](Half& H, int ps) {
+        H.phase = -((grp * lanes + ps) * kChainLag + grp * slack) - 1;
+        H.turn = 0;
+    };
+    start_clock(lo, 2 * pair);
+    start_clock(hi, 2 * pair + 1);
     auto schedule = [&](Half& H, int ps, bool high, int round) {
         const int g = grp * lanes + ps;  // the slot among all of the buffer's
-        const int rel = round - (g * kChainLag + grp * slack);
-        const int j = rel >= 0 ? (rel / cycle) * slots + g : ch.npass;
-        H.t = rel >= 0 ? rel % cycle - 1 : 0;
+        if (++H.phase == cycle) {
+            H.phase = 0;
+            ++H.turn;
+        }
+        const int j = H.phase >= 0 ? H.turn * slots + g : ch.npass;
+        H.t = H.phase >= 0 ? H.phase - 1 : 0;
         const bool active = j < ch.npass && H.t < pass_rounds - 1;
         H.run = active && H.t >= 0;
         H.fetch = active && H.t < 0;
@@ -678,9 +705,17 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
 
     ChainSync sync{};
     if constexpr (GROUPED) sync.init(ch, b, grp);
+#ifdef SN_CHAIN_TIMING
+    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime(), keep_[2] = {0, 0};
+#endif
     for (int round = 0; round < total; ++round) {
+#ifdef SN_CHAIN_TIMING
+        last_ = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();  // (waits for this wave's stores and loads, then for everybody's)
+        SN_TICK(0);
         if constexpr (GROUPED) sync.enter(round, pair == 0, tid);
+        SN_TICK(1);
         schedule(lo, 2 * pair, false, round);
         schedule(hi, 2 * pair + 1, true, round);
         if (!lo.run && !hi.run) {
@@ -688,8 +723,17 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
                 if (lo.fetch) prime(lo, false);
                 if (hi.fetch) prime(hi, true);
             }
+#ifdef SN_CHAIN_TIMING
+            acc_[0] = keep_[0];  // rounds without rows are not counted
+            acc_[1] = keep_[1];
+#endif
             continue;
         }
+#ifdef SN_CHAIN_TIMING
+        keep_[0] = acc_[0];
+        keep_[1] = acc_[1];
+        acc_[5] += 1;
+#endif
         const int copy = round & 1;
         const unsigned refresh = (lo.run && lo.t > 0 ? kLo : 0u) | (hi.run && hi.t > 0 ? kHi : 0u);
         if (refresh && recv) {  // the ghosts take over what the seam lanes held after the block before
@@ -720,10 +764,25 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
             for (int c = 0; c < 8; ++c) X[3 + c] = E[c];
             unsigned T = ((X[0] + X[1]) + (X[2] + X[3])) + ((X[4] + X[5]) + X[6]);
             Row o;
+            if constexpr (THREADS <= 512) {
+                // two windows slide side by side (columns 0 .. 3 and 4 .. 7): with one or two waves on a SIMD a row is as long
+                // as its longest chain of dependent instructions, and one window sliding over eight columns is fourteen deep
+                unsigned T4 = ((X[4] + X[5]) + (X[6] + X[7])) + ((X[8] + X[9]) + X[10]);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                o.v[c] = (T >> 4) & 0x00ff00ffu;  // (sum / 16) wraps to uint8_t, SangNom2.cpp:152; integer sums: any order
-                if (c < 7) T = (T - X[c]) + X[c + 7];
+                for (int c = 0; c < 4; ++c) {
+                    o.v[c] = (T >> 4) & 0x00ff00ffu;  // (sum / 16) wraps to uint8_t, SangNom2.cpp:152; integer sums: any order
+                    o.v[4 + c] = (T4 >> 4) & 0x00ff00ffu;
+                    if (c < 3) {
+                        T = (T - X[c]) + X[c + 7];
+                        T4 = (T4 - X[4 + c]) + X[c + 11];
+                    }
+                }
+            } else {  // sixteen waves: bound by what the CU issues, three instructions fewer
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    o.v[c] = (T >> 4) & 0x00ff00ffu;
+                    if (c < 7) T = (T - X[c]) + X[c + 7];
+                }
             }
             {   // o.v[c] = low-pass byte | high-pass byte << 16  ->  eight bytes per pass
                 const unsigned t01 = __builtin_amdgcn_perm(o.v[1], o.v[0], 0x06020400u), t23 = __builtin_amdgcn_perm(o.v[3], o.v[2], 0x06020400u);
@@ -757,6 +816,7 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
                 }
             }
         };
+        SN_TICK(2);
         if (lo.run && hi.run && K * lo.t + K < rows && K * hi.t + K < rows) {  // the steady state: no condition per row
 #pragma unroll
             for (int u = 0; u < K; ++u) row_body(u, true, true, std::integral_constant<bool, true>{});
@@ -771,14 +831,32 @@ __global__ void __launch_bounds__(GROUPED ? kChain8Threads / 2 : kChain8Threads)
                 if (hi.fetch) prime(hi, true);
             }
         }
+        SN_TICK(3);
         const bool more0 = lo.run && K * (lo.t + 1) < rows - 1, more1 = hi.run && K * (hi.t + 1) < rows - 1;
         if ((more0 || more1) && (pub_right || pub_left)) {
             unsigned* to = pub_right ? mb_at((round + 1) & 1, wave + 1, 0, slot) : mb_at((round + 1) & 1, wave - 1, 1, slot);
 #pragma unroll
             for (int c = 0; c < 8; ++c) to[c] = prev.v[c];
         }
+        SN_TICK(4);
     }
+#ifdef SN_CHAIN_TIMING
+    if (lane == 0)
+        for (int k = 0; k < 6; ++k) atomicAdd(&sn_chain_cycles[k], acc_[k]);
+#endif
 }
+
+#ifdef SN_CHAIN_TIMING
+extern "C" __attribute__((visibility("default"))) int sn_debug_chain_cycles(unsigned long long out[6], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sn_chain_cycles), sizeof(unsigned long long) * 6) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sn_chain_cycles), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 // The chain for 9..16-bit samples: the same schedule around the row body of k_smooth_u16_strips.  GROUPED: over several
 // workgroups per buffer as k_smooth_u8_chain<true> -- with one pass per wave a workgroup of sixteen waves only holds
@@ -1739,6 +1817,7 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
     const int pass_rounds = 1 + (rows - 1 + v3c::K - 1) / v3c::K;
     const int busy = lanes * groups * kChainLag + groups * (groups > 1 ? chain.slack : 0);  // rounds until a slot may take its next pass
     const int cycle = pass_rounds > busy ? pass_rounds : busy;
+    if (groups == 1 && chain.npass < lanes) lanes = bytes == 1 ? (chain.npass + 1) & ~1 : chain.npass;  // a short chain: no idle waves at the barrier
     const int sets = bytes == 1 ? lanes / 2 : lanes;  // sets of nw waves (8-bit: a set carries two passes)
     const size_t lds = (size_t)sets * 2 * nw * 2 * v3c::GH * 8 * sizeof(unsigned);
     const dim3 grid(kBuffers * groups, nchains), block(sets * nw * 64);
@@ -1751,9 +1830,11 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
     else if (bytes == 2)
         hipLaunchKernelGGL(k_smooth_u16_chain<false>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else if (groups > 1)
-        hipLaunchKernelGGL(k_smooth_u8_chain<true>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+        hipLaunchKernelGGL((k_smooth_u8_chain<true, kChain8Threads / 2>), grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+    else if ((int)block.x <= kChain8Threads / 2)
+        hipLaunchKernelGGL((k_smooth_u8_chain<false, kChain8Threads / 2>), grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     else
-        hipLaunchKernelGGL(k_smooth_u8_chain<false>, grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
+        hipLaunchKernelGGL((k_smooth_u8_chain<false, kChain8Threads>), grid, block, lds, st, pool, chain, nw, lanes, pass_rounds, cycle);
     return hipGetLastError();
 }
 
