@@ -960,7 +960,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         }
         const int par = (r / K) & 1;
         if (r > r0 && (r - 1) % K == 0) {
+#ifndef SN_X_NO_SEAM_BARRIER
             __syncthreads();
+#endif
             if (recv_left || recv_right) {
                 const unsigned* from = reinterpret_cast<const unsigned*>(mb.at(par, wave, recv_left ? 0 : 1, slot));
                 auto merge = [&](int b, unsigned (&Ab)[PXL]) {

@@ -120,7 +120,7 @@ def test_device_batch_matches_oracle(hip_lib):
     dev = torch.device("cuda:0")
     with SangNom2(clip, max_batch=N, **kw) as flt:
         assert flt.info().history_free == 1
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).to(dev) for p in range(3)]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).pin_memory().to(dev) for p in range(3)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(3)]
         torch.cuda.synchronize()
         parity = [1, 0, 1, 1, 0]
@@ -143,7 +143,7 @@ def test_device_batch_history_carrying(hip_lib):
     ora = Oracle(oracle_cfg(clip))
     with SangNom2(clip, max_batch=N) as flt:
         assert flt.info().history_free == 0
-        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).to(dev)]
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).pin_memory().to(dev)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(0), dtype=torch.uint8, device=dev)]
         flt.process_batch(src, dst)
         flt.synchronize()
@@ -295,7 +295,7 @@ def test_fused_equals_pool_at_full_size(hip_lib):
     g = torch.Generator(device=dev)
     g.manual_seed(99)
     src = [torch.randint(0, 256, (N, 2160, 3840), device=dev, generator=g, dtype=torch.uint8)]
-    src[0][1] = torch.from_numpy(synth.plane(2160, 3840, 1, 8, "checker", 1)).to(dev)
+    src[0][1] = torch.from_numpy(synth.plane(2160, 3840, 1, 8, "checker", 1)).pin_memory().to(dev)
     outs = {}
     for mode in ("fused", "pool"):
         with SangNom2(clip, max_batch=N, mode=mode) as flt:
@@ -332,7 +332,7 @@ def test_full_size_fused_equals_pool_and_oracle(hip_lib, name, fmt, w, h, kw, N)
     shapes = [(h >> (clip.subh if p else 0), w >> (clip.subw if p else 0)) for p in range(clip.planes)]
     src = [torch.randint(0, 256, (N,) + sh, device=dev, generator=g, dtype=torch.uint8) for sh in shapes]
     for p, sh in enumerate(shapes):  # one hard 0/255 checker frame: maximises the wrap paths of stage 2
-        src[p][N - 1] = torch.from_numpy(synth.plane(sh[0], sh[1], 1, 8, "checker", p)).to(dev)
+        src[p][N - 1] = torch.from_numpy(synth.plane(sh[0], sh[1], 1, 8, "checker", p)).pin_memory().to(dev)
     outs = {}
     for mode in ("fused", "pool"):
         with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
@@ -436,7 +436,7 @@ def test_pool_stage2_kernels_match_oracle(hip_lib, fmt, w):
     want = [ora.process(fr, parity=1) for fr in frames]
     with SangNom2(clip, max_batch=N, mode="pool", **kw) as flt:
         assert bool(flt.info().history_free) == history_free
-        src = [torch.from_numpy(np.stack([fr[0] for fr in frames]).view(vdt)).to(dev)]
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames]).view(vdt)).pin_memory().to(dev)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(0), dtype=tdt, device=dev)]
         # one launch of three frames and one of ten; a history-carrying clip (1000 wide) runs frame by frame whatever
         # the launch holds, and its frames must come in the oracle's order from a new instance
@@ -485,7 +485,7 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
     with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
         assert not flt.info().history_free
         view = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).to(dev) for p in range(clip.planes)]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).pin_memory().to(dev) for p in range(clip.planes)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
         for rnd in range(2):  # the second launch starts from the pool the first one left
@@ -538,7 +538,7 @@ def test_chain_over_several_workgroups_per_buffer_matches_oracle(hip_lib, monkey
         assert not flt.info().history_free
         assert flt.get_policy().chain == groups
         view = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).to(dev) for p in range(clip.planes)]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(view)).pin_memory().to(dev) for p in range(clip.planes)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=src[p].dtype, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
         for rnd in range(2):  # the second launch starts from the pool the first one left
@@ -585,7 +585,7 @@ def test_a_chain_that_timed_out_fails_every_later_call(hip_lib):
     frames = make_frames(clip, "noise", 12, seed0=5)
     dev = torch.device("cuda:0")
     with SangNom2(clip, max_batch=12) as flt:
-        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).to(dev)]
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).pin_memory().to(dev)]
         dst = [torch.zeros((12,) + flt.plane_shape_out(0), dtype=torch.uint8, device=dev)]
         torch.cuda.synchronize()
         flt.process_batch(src, dst)
@@ -618,7 +618,7 @@ def test_chain_can_be_switched_off(hip_lib, monkeypatch):
     ora = Oracle(oracle_cfg(clip))
     dev = torch.device("cuda:0")
     with SangNom2(clip, max_batch=4) as flt:
-        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).to(dev)]
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).pin_memory().to(dev)]
         dst = [torch.zeros((4,) + flt.plane_shape_out(0), dtype=torch.uint8, device=dev)]
         torch.cuda.synchronize()
         flt.process_batch(src, dst)
@@ -641,7 +641,7 @@ def test_batch_larger_than_the_scratch_budget_runs_in_chunks(hip_lib, monkeypatc
     dev = torch.device("cuda:0")
     tdt = {np.uint8: torch.uint8, np.uint16: torch.int16}[clip.dtype]
     with SangNom2(clip, max_batch=N, mode=mode, **kw) as flt:
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(np.int16 if clip.bytes == 2 else np.uint8)).to(dev)
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(np.int16 if clip.bytes == 2 else np.uint8)).pin_memory().to(dev)
                for p in range(clip.planes)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
@@ -755,7 +755,7 @@ def test_fresh_pool_equals_a_new_instance_per_frame_and_plane(hip_lib, fmt, w, h
     vt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
     with SangNom2(clip, fresh_pool=True, max_batch=N, **kw) as flt:
         assert flt.info().history_free == 1
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(vt)).to(dev) for p in range(clip.planes)]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(vt)).pin_memory().to(dev) for p in range(clip.planes)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
         parity = [f & 1 for f in range(N)]
@@ -781,7 +781,7 @@ def test_turn_device_is_avisynths_turnright_turnleft(hip_lib, fmt, w, h):
     vt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
     a = np.stack([synth.frame(clip, "noise", seed=s)[0] for s in range(2)])
     with SangNom2(ClipFormat(width=64, height=32, bytes=clip.bytes, bits=clip.bits)) as flt:
-        src = torch.from_numpy(a.view(vt)).to(dev)
+        src = torch.from_numpy(a.view(vt)).pin_memory().to(dev)
         for direction, k in ((+1, -1), (-1, 1)):  # TurnRight = clockwise = rot90(k=-1)
             dst = torch.zeros((2, w, h), dtype=src.dtype, device=dev)
             torch.cuda.synchronize()
@@ -825,7 +825,7 @@ def test_anti_aliasing_idiom_on_the_device(hip_lib, fmt, w, h, kw):
     dev = torch.device("cuda:0")
     vt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
     with SangNomAA(clip, max_batch=N, **kw) as aa:
-        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(vt)).to(dev) for p in range(clip.planes)]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames]).view(vt)).pin_memory().to(dev) for p in range(clip.planes)]
         dst = [torch.zeros_like(s) for s in src]
         torch.cuda.synchronize()
         aa.process_batch(src, dst)
@@ -912,7 +912,7 @@ def test_legacy_sangnom_wrapper_and_single_frame_device_entry(hip_lib):
                 want = ora.process(fr, parity=f)
                 got = flt.get_frame(fr, parity=f)
                 dev = torch.device("cuda:0")
-                src = [torch.from_numpy(pl).to(dev) for pl in fr]
+                src = [torch.from_numpy(pl).pin_memory().to(dev) for pl in fr]
                 dst = [torch.zeros_like(s) for s in src]
                 torch.cuda.synchronize()
                 for p in range(3):
@@ -922,7 +922,7 @@ def test_legacy_sangnom_wrapper_and_single_frame_device_entry(hip_lib):
     # the single-frame device entry point: same frame, same result (history-free clip)
     with SangNom2(clip, aa=30) as flt:
         want = Oracle(oracle_cfg(clip, aa=30)).process(frames[0])
-        src = [torch.from_numpy(pl).to(dev) for pl in frames[0]]
+        src = [torch.from_numpy(pl).pin_memory().to(dev) for pl in frames[0]]
         dst = [torch.zeros_like(s) for s in src]
         torch.cuda.synchronize()
         flt.get_frame_device(src, dst)
@@ -1078,7 +1078,7 @@ def test_field_orders_and_double_height_at_2160_rows_through_the_sweeps(hip_lib,
     dev = torch.device("cuda:0")
     npdt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
     with SangNom2(clip, max_batch=N, mode="fused", **kw) as flt:
-        src = [torch.from_numpy(np.stack([fr[0] for fr in frames]).view(npdt)).to(dev)]
+        src = [torch.from_numpy(np.stack([fr[0] for fr in frames]).view(npdt)).pin_memory().to(dev)]
         dst = [torch.zeros((N,) + flt.plane_shape_out(0), dtype=src[0].dtype, device=dev)]
         torch.cuda.synchronize()
         flt.process_batch(src, dst, parity)
@@ -1344,7 +1344,7 @@ def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, 
     tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
     with SangNom2(clip, max_batch=n, **kw) as flt:
         flt.set_bands(6, 0)
-        src = [torch.from_numpy(np.stack([frames[f][p] for f in range(n)]).view({1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes])).to(dev)
+        src = [torch.from_numpy(np.stack([frames[f][p] for f in range(n)]).view({1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes])).pin_memory().to(dev)
                for p in range(clip.planes)]
         dst = [torch.zeros((n,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
         torch.cuda.synchronize()
