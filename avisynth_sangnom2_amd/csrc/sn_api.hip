@@ -729,6 +729,8 @@ static bool ensure_chroma_chains(Context* c, int slot0, int n, hipStream_t st)
         int64_t fit = scratch_budget(c) / 8 / c->pool.slot_bytes;
         const int64_t want = 3 * (int64_t)(c->slots < kMaxBandSlots ? c->slots : kMaxBandSlots);
         if (fit > want) fit = want;
+        const int64_t addressable = (int64_t)0xfffffffe / c->pool.slot_bytes;  // the chain kernels address the ring with 32-bit offsets
+        if (fit > addressable) fit = addressable;
         fit -= fit % 3;
         if (fit < 3) return false;
         if (hipMalloc(reinterpret_cast<void**>(&c->chain_base), (size_t)c->pool.slot_bytes * fit) != hipSuccess) {
@@ -1183,6 +1185,12 @@ static int ensure_chain(Context* c, int pn, hipStream_t st)
     const int64_t want = (int64_t)(c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth) * pn;
     fit = fit > want ? want : fit;
     fit = fit > 1536 ? 1536 : fit;
+    const int64_t addressable = (int64_t)0xfffffffe / c->pool.slot_bytes - 1;  // the chain kernels address the ring with 32-bit offsets
+    fit = fit > addressable ? addressable : fit;
+    if (addressable < 2 * pn) {  // (a pool slot of more than 600 MB: no chain, the frame-by-frame path)
+        c->chain_slots = -1;
+        return SN_CHAIN_UNAVAILABLE;
+    }
     if (fit < 2 * pn) fit = 2 * pn;
     c->chain_slots = (int)fit + 1;
     if (hipMalloc(reinterpret_cast<void**>(&c->chain_base), (size_t)c->pool.slot_bytes * c->chain_slots) != hipSuccess) {

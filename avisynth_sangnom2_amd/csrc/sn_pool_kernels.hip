@@ -614,11 +614,20 @@ __global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, Chai
     const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
 
     // state of the two passes this wave is working on (lo: low halves, pass slot 2 * pair; hi: high halves)
+    // Addresses: ONE buffer resource over the whole ring; a pass's slot and cost buffer and the pool row are wave-uniform
+    // and travel in the scalar offset, a lane adds 32 bits of its own -- its columns, plus which of the two slots it reads
+    // (its own where the pass's k_prepare wrote, the one of the pass before it elsewhere).  Per load one select, per store
+    // nothing, where 64-bit pointers per lane took seven and four instructions; lanes that store nothing carry an offset
+    // the range check rejects.  (The ring stays below 4 GB for that: ensure_chain, sn_api.hip.)
+    constexpr unsigned kNoAccess = 0xffffffffu;
+    constexpr int kAux = GROUPED ? 16 : 0;  // sc1: coherent at agent scope, as the atomics of the 16-bit and float chains
+    const unsigned long long ring_bytes = (unsigned long long)pool.slot_bytes * (unsigned long long)pool.slot_mod;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pool.base, 0, ring_bytes < 0xfffffffeull ? (int)(unsigned)ring_bytes : (int)0xfffffffeu, 0x00020000);
     struct Half {
-        const uint8_t* own;     // this lane's columns in the pass's slot ...
-        const uint8_t* before;  // ... and in the slot of the pass before it
-        uint8_t* out;
-        int fresh_rows;         // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
+        unsigned vo_fresh;      // this lane's offset for rows 1 .. nr: in the pass's own slot where its k_prepare wrote ...
+        unsigned vo_stale;      // ... and for every other row: in the slot of the pass before it
+        unsigned vo_out;        // where it stores (kNoAccess: ghost and dead lanes)
+        int nr;                 // rows 1 .. nr of columns < w were written by the pass's k_prepare
         int t;                  // block of K rows the pass is at in this round
         bool run, fetch;        // the pass has rows in this round / is in its first round
         int phase, turn;        // the slot's clock: rounds since it last took a pass (< 0: not started yet), passes taken so far
@@ -626,26 +635,19 @@ __global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, Chai
         uint2 first[3];         // GROUPED: rows 0 .. 2, from the pass's first round's start to its end
     };
     constexpr int kAhead = K;
-    const uint8_t* idle = pool.base + (size_t)b * bufsz + x0;  // somewhere mapped for the loads of a half without a pass
-    Half lo{idle, idle, nullptr, 0, 0, false, false, 0, 0, {}, {}}, hi{idle, idle, nullptr, 0, 0, false, false, 0, 0, {}, {}};
+    Half lo{kNoAccess, kNoAccess, kNoAccess, 0, 0, false, false, 0, 0, {}, {}}, hi{kNoAccess, kNoAccess, kNoAccess, 0, 0, false, false, 0, 0, {}, {}};
     Row prev{}, cur{}, nxt{};
     auto load = [&](const Half& H, int row) {
         row = row < 0 ? 0 : row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
-        const uint8_t* from = row >= 1 && row <= H.fresh_rows ? H.own : H.before;
-        if constexpr (GROUPED) {
-            const unsigned long long q = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(from + (size_t)row * se), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
-            return make_uint2((unsigned)q, (unsigned)(q >> 32));
-        } else {
-            return *reinterpret_cast<const uint2*>(from + (size_t)row * se);
-        }
+        const bool fresh = row >= 1 && row <= H.nr;  // (uniform)
+        const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(fresh ? H.vo_fresh : H.vo_stale), row * se, kAux);
+        return make_uint2((unsigned)q[0], (unsigned)q[1]);
     };
-    auto store = [&](uint8_t* to, uint2 q) {
-        if constexpr (GROUPED)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(to), (unsigned long long)q.x | (unsigned long long)q.y << 32, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        else
-            *reinterpret_cast<uint2*>(to) = q;
+    auto store = [&](const Half& H, int row, uint2 q) {
+        u32x2 v;
+        v[0] = q.x;
+        v[1] = q.y;
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)H.vo_out, row * se, kAux);
     };
     // a pass's rows 0 .. 2 into its half of the registers
     auto prime_from = [&](uint2 q0, uint2 q1, uint2 q2, bool high) {
@@ -685,10 +687,12 @@ __global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, Chai
         if (H.fetch) {
             const int k = j % ch.pn;
             const int64_t s_own = (origin + 1 + j) % pool.slot_mod, s_before = (origin + j) % pool.slot_mod;
-            H.own = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
-            H.before = pool.base + s_before * pool.slot_bytes + (size_t)b * bufsz + x0;
-            H.out = pool.base + s_own * pool.slot_bytes + (size_t)b * bufsz + x0;
-            H.fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
+            const unsigned own_off = (unsigned)(s_own * pool.slot_bytes + (int64_t)b * (int64_t)bufsz);        // (uniform; the ring is
+            const unsigned before_off = (unsigned)(s_before * pool.slot_bytes + (int64_t)b * (int64_t)bufsz);  // smaller than 4 GB)
+            H.vo_stale = before_off + x0;
+            H.vo_fresh = (x0 < ch.w[k] ? own_off : before_off) + x0;
+            H.vo_out = real ? own_off + x0 : kNoAccess;
+            H.nr = ch.nr[k];
             if constexpr (LATE_PRIME) {  // only issued here: prime() takes them in when the round is over
 #pragma unroll
                 for (int u = 0; u < 3; ++u) H.first[u] = load(H, u);
@@ -792,10 +796,8 @@ __global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, Chai
                 qa.y = __builtin_amdgcn_perm(t67, t45, 0x05040100u);
                 qb.x = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
                 qb.y = __builtin_amdgcn_perm(t67, t45, 0x07060302u);
-                if (real) {
-                    if (BOTH || v0) store(lo.out + (size_t)r0 * se, qa);
-                    if (BOTH || v1) store(hi.out + (size_t)r1 * se, qb);
-                }
+                if (BOTH || v0) store(lo, r0, qa);  // (lanes that keep nothing: dropped by the range check, no branch)
+                if (BOTH || v1) store(hi, r1, qb);
             }
             if (BOTH || (v0 && v1)) {
                 prev = o;
@@ -1809,6 +1811,7 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
     for (int k = 0; k < chain.pn; ++k)
         if (chain.w[k] % 8 != 0 || chain.nr[k] >= pool.bh) return hipErrorInvalidValue;
     const int nw = v3c::strips_for(pool.stride_e / 8);
+    if (bytes == 1 && (int64_t)pool.slot_bytes * pool.slot_mod > (int64_t)0xfffffffe) return hipErrorInvalidValue;  // 32-bit offsets into the ring
     if (groups > 1) {
         if (groups != pool_chain_groups(bytes, pool.stride_e, groups) || !chain.flags || !chain.status || chain.slack < 0) return hipErrorInvalidValue;
         lanes = (bytes == 1 ? 2 : 1) * (chain_waves(bytes, groups) / nw);  // per workgroup (8-bit: two passes per set of nw waves)
