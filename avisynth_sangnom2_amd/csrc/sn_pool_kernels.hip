@@ -424,32 +424,6 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs po
 // ---- chains over several workgroups per buffer (see k_smooth_u8_chain): the pieces the three sample types share ----
 constexpr int kChainSpinLimit = 1 << 20;  // x (s_sleep 8 + a load from memory): two seconds and more
 
-// sixteen bytes of a pool row; COHERENT: as agent-scope relaxed atomics (global_load / global_store ... sc1), two of eight
-// bytes each -- a row is only ever read after the round counters said its writer is done with it
-template <bool COHERENT>
-__device__ __forceinline__ uint4 chain_load16(const void* p)
-{
-    if constexpr (COHERENT) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
-    } else {
-        return *reinterpret_cast<const uint4*>(p);
-    }
-}
-template <bool COHERENT>
-__device__ __forceinline__ void chain_store16(void* p, uint4 v)
-{
-    if constexpr (COHERENT) {
-        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-        __hip_atomic_store(q, (unsigned long long)v.x | (unsigned long long)v.y << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, (unsigned long long)v.z | (unsigned long long)v.w << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *reinterpret_cast<uint4*>(p) = v;
-    }
-}
-
 // The round counters of a buffer's workgroups.  enter(), right after the barrier that opens round `round`: the workgroup
 // publishes "rounds < round are complete" (the barrier waited for its stores), and the waves of its first slot make sure
 // the workgroup before it has completed round `round - 1 - slack` -- with the value they fetched while the round before
@@ -640,7 +614,8 @@ __global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, Chai
     auto load = [&](const Half& H, int row) {
         row = row < 0 ? 0 : row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
         const bool fresh = row >= 1 && row <= H.nr;  // (uniform)
-        const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(fresh ? H.vo_fresh : H.vo_stale), row * se, kAux);
+        const unsigned of = H.vo_fresh, os = H.vo_stale;
+        const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(fresh ? of : os), row * se, kAux);
         return make_uint2((unsigned)q[0], (unsigned)q[1]);
     };
     auto store = [&](const Half& H, int row, uint2 q) {
@@ -914,18 +889,25 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
     const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
     const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
 
-    // state of the pass this wave is working on
-    const uint16_t* own = nullptr;   // this lane's columns in the pass's slot ...
-    const uint16_t* before = nullptr;  // ... and in the slot of the pass before it
-    uint16_t* out = nullptr;
-    int fresh_rows = 0;  // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
+    // state of the pass this wave is working on; addresses as in k_smooth_u8_chain: one buffer resource over the ring, the
+    // slot, cost buffer and pool row in the scalar offset, 32 bits per lane (a row is ONE sixteen-byte access, coherent or not)
+    constexpr unsigned kNoAccess = 0xffffffffu;
+    constexpr int kAux = GROUPED ? 16 : 0;  // sc1
+    const unsigned long long ring_bytes = (unsigned long long)pool.slot_bytes * (unsigned long long)pool.slot_mod;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pool.base, 0, ring_bytes < 0xfffffffeull ? (int)(unsigned)ring_bytes : (int)0xfffffffeu, 0x00020000);
+    unsigned vo_fresh = kNoAccess;  // this lane's offset for rows 1 .. nr: in the pass's own slot where its k_prepare wrote ...
+    unsigned vo_stale = kNoAccess;  // ... and for every other row: in the slot of the pass before it
+    unsigned vo_out = kNoAccess;    // where it stores (kNoAccess: ghost and dead lanes)
+    int nr = 0;
     Row prev{}, cur{}, nxt{};
     constexpr int kAhead = K;
     uint4 ring[kAhead] = {};
     auto load = [&](int row) {
         row = row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
-        const uint16_t* from = row >= 1 && row <= fresh_rows ? own : before;
-        return chain_load16<GROUPED>(from + (size_t)row * se);
+        const bool fresh = row >= 1 && row <= nr;  // (uniform)
+        const unsigned of = vo_fresh, os = vo_stale;  // (by value: a conditional between the two VARIABLES would take their addresses)
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(fresh ? of : os), row * se * 2, kAux);
+        return make_uint4(q[0], q[1], q[2], q[3]);
     };
 
     ChainSync sync{};
@@ -941,10 +923,12 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
         if (t < 0) {  // the pass's first rows
             const int k = j % ch.pn;
             const int64_t s_own = (origin + 1 + j) % pool.slot_mod, s_before = (origin + j) % pool.slot_mod;
-            own = reinterpret_cast<const uint16_t*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
-            before = reinterpret_cast<const uint16_t*>(pool.base + s_before * pool.slot_bytes) + (size_t)b * bufsz + x0;
-            out = reinterpret_cast<uint16_t*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
-            fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
+            const unsigned own_off = (unsigned)(s_own * pool.slot_bytes + (int64_t)b * (int64_t)bufsz * 2);        // (uniform; the ring is
+            const unsigned before_off = (unsigned)(s_before * pool.slot_bytes + (int64_t)b * (int64_t)bufsz * 2);  // smaller than 4 GB)
+            vo_stale = before_off + x0 * 2;
+            vo_fresh = (x0 < ch.w[k] ? own_off : before_off) + x0 * 2;
+            vo_out = real ? own_off + x0 * 2 : kNoAccess;
+            nr = ch.nr[k];
             prev = unpack(load(0));
             cur = unpack(load(1));
             nxt = unpack(load(2));
@@ -979,13 +963,13 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
                     o.v[m] = (T >> 4) & 0xffffu;
                     if (m < 7) T = (T - X[m]) + X[m + 7];
                 }
-                if (real) {
-                    uint4 q;
-                    q.x = o.v[0] | (o.v[1] << 16);
-                    q.y = o.v[2] | (o.v[3] << 16);
-                    q.z = o.v[4] | (o.v[5] << 16);
-                    q.w = o.v[6] | (o.v[7] << 16);
-                    chain_store16<GROUPED>(out + (size_t)r * se, q);
+                {
+                    u32x4 q;
+                    q[0] = o.v[0] | (o.v[1] << 16);
+                    q[1] = o.v[2] | (o.v[3] << 16);
+                    q[2] = o.v[4] | (o.v[5] << 16);
+                    q[3] = o.v[6] | (o.v[7] << 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)vo_out, r * se * 2, kAux);  // (lanes that keep nothing: dropped by the range check)
                 }
                 prev = o;
                 cur = nxt;
@@ -1056,21 +1040,28 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
     const int last_slot = (ch.npass - 1) % slots;  // the chain is over when its last pass is: no rounds for slots nothing fills
     const int total = ((ch.npass - 1) / slots) * cycle + last_slot * kChainLag + (last_slot / lanes) * slack + pass_rounds;
 
-    // state of the pass this wave is working on
-    const float* own = nullptr;   // this lane's columns in the pass's slot ...
-    const float* before = nullptr;  // ... and in the slot of the pass before it
-    float* out = nullptr;
-    int fresh_rows = 0;  // rows 1 .. fresh_rows of this lane's columns were written by the pass's k_prepare
+    // state of the pass this wave is working on; addresses as in k_smooth_u8_chain: one buffer resource over the ring, the
+    // slot, cost buffer and pool row in the scalar offset, 32 bits per lane (a row is ONE sixteen-byte access, coherent or not)
+    constexpr unsigned kNoAccess = 0xffffffffu;
+    constexpr int kAux = GROUPED ? 16 : 0;  // sc1
+    const unsigned long long ring_bytes = (unsigned long long)pool.slot_bytes * (unsigned long long)pool.slot_mod;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pool.base, 0, ring_bytes < 0xfffffffeull ? (int)(unsigned)ring_bytes : (int)0xfffffffeu, 0x00020000);
+    unsigned vo_fresh = kNoAccess;  // this lane's offset for rows 1 .. nr: in the pass's own slot where its k_prepare wrote ...
+    unsigned vo_stale = kNoAccess;  // ... and for every other row: in the slot of the pass before it
+    unsigned vo_out = kNoAccess;    // where it stores (kNoAccess: ghost and dead lanes)
+    int nr = 0;
     Row prev{}, cur{}, nxt{};
     constexpr int kAhead = K;
     Raw ring[kAhead] = {};
     auto load = [&](int row) {
         row = row <= pool.bh ? row : pool.bh;  // past the end: loaded, never used
-        const float4* from = reinterpret_cast<const float4*>((row >= 1 && row <= fresh_rows ? own : before) + (size_t)row * se);
+        const bool fresh = row >= 1 && row <= nr;  // (uniform)
+        const unsigned of = vo_fresh, os = vo_stale;  // (by value, see k_smooth_u16_chain)
+        const int voff = (int)(fresh ? of : os);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, row * se * 4, kAux), c = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, row * se * 4 + 16, kAux);
         Raw q;
-        const uint4 a = chain_load16<GROUPED>(from), c = chain_load16<GROUPED>(from + 1);
-        q.lo = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-        q.hi = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
+        q.lo = make_float4(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3]));
+        q.hi = make_float4(__uint_as_float(c[0]), __uint_as_float(c[1]), __uint_as_float(c[2]), __uint_as_float(c[3]));
         return q;
     };
 
@@ -1087,10 +1078,12 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
         if (t < 0) {  // the pass's first rows
             const int k = j % ch.pn;
             const int64_t s_own = (origin + 1 + j) % pool.slot_mod, s_before = (origin + j) % pool.slot_mod;
-            own = reinterpret_cast<const float*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
-            before = reinterpret_cast<const float*>(pool.base + s_before * pool.slot_bytes) + (size_t)b * bufsz + x0;
-            out = reinterpret_cast<float*>(pool.base + s_own * pool.slot_bytes) + (size_t)b * bufsz + x0;
-            fresh_rows = x0 < ch.w[k] ? ch.nr[k] : 0;
+            const unsigned own_off = (unsigned)(s_own * pool.slot_bytes + (int64_t)b * (int64_t)bufsz * 4);        // (uniform; the ring is
+            const unsigned before_off = (unsigned)(s_before * pool.slot_bytes + (int64_t)b * (int64_t)bufsz * 4);  // smaller than 4 GB)
+            vo_stale = before_off + x0 * 4;
+            vo_fresh = (x0 < ch.w[k] ? own_off : before_off) + x0 * 4;
+            vo_out = real ? own_off + x0 * 4 : kNoAccess;
+            nr = ch.nr[k];
             prev = unpack(load(0));
             cur = unpack(load(1));
             nxt = unpack(load(2));
@@ -1122,10 +1115,15 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
 #pragma unroll
                 for (int m = 0; m < 8; ++m)  // left to right, SangNom2.cpp:152
                     o.v[m] = ((((((X[m] + X[m + 1]) + X[m + 2]) + X[m + 3]) + X[m + 4]) + X[m + 5]) + X[m + 6]) * 0.0625f;
-                if (real) {
-                    float4* q = reinterpret_cast<float4*>(out + (size_t)r * se);
-                    chain_store16<GROUPED>(q, make_uint4(__float_as_uint(o.v[0]), __float_as_uint(o.v[1]), __float_as_uint(o.v[2]), __float_as_uint(o.v[3])));
-                    chain_store16<GROUPED>(q + 1, make_uint4(__float_as_uint(o.v[4]), __float_as_uint(o.v[5]), __float_as_uint(o.v[6]), __float_as_uint(o.v[7])));
+                {
+                    u32x4 qa, qb;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        qa[m] = __float_as_uint(o.v[m]);
+                        qb[m] = __float_as_uint(o.v[4 + m]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(qa, rs, (int)vo_out, r * se * 4, kAux);  // (lanes that keep nothing: dropped by the range check)
+                    __builtin_amdgcn_raw_buffer_store_b128(qb, rs, (int)vo_out, r * se * 4 + 16, kAux);
                 }
                 prev = o;
                 cur = nxt;
@@ -1811,7 +1809,7 @@ hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainAr
     for (int k = 0; k < chain.pn; ++k)
         if (chain.w[k] % 8 != 0 || chain.nr[k] >= pool.bh) return hipErrorInvalidValue;
     const int nw = v3c::strips_for(pool.stride_e / 8);
-    if (bytes == 1 && (int64_t)pool.slot_bytes * pool.slot_mod > (int64_t)0xfffffffe) return hipErrorInvalidValue;  // 32-bit offsets into the ring
+    if ((int64_t)pool.slot_bytes * pool.slot_mod > (int64_t)0xfffffffe) return hipErrorInvalidValue;  // 32-bit offsets into the ring
     if (groups > 1) {
         if (groups != pool_chain_groups(bytes, pool.stride_e, groups) || !chain.flags || !chain.status || chain.slack < 0) return hipErrorInvalidValue;
         lanes = (bytes == 1 ? 2 : 1) * (chain_waves(bytes, groups) / nw);  // per workgroup (8-bit: two passes per set of nw waves)
