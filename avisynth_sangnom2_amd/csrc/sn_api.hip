@@ -986,7 +986,7 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         // Round 3: U and V as ONE chain of two passes per frame (k_smooth_*_chain; 8-bit: both in the same waves, V fifteen rows
         // behind U) on ring slots 3 f (luma's smoothed rows), 3 f + 1 (U), 3 f + 2 (V), instead of two stage-2 launches one after
         // the other: a 2160p YUV420P8 frame 0.617 -> 0.486 ms on the device, YUV420P16 0.73 -> 0.65.  Not for float samples: two
-        // float passes on one CU take longer than one after the other (0.95 -> 1.10 ms).
+        // float passes on one CU take longer than one after the other (0.94 -> 1.11 ms).
         const bool chroma_chain = c->cfg.bytes_per_sample != 4 && pa[1].enabled && pa[2].enabled && pa[1].w == pa[2].w && pa[1].h_out == pa[2].h_out && pa[1].w % 8 == 0 &&
                                   ensure_chroma_chains(c, slot0, n, st);
         sn::PoolArgs ring = c->pool;

@@ -1791,9 +1791,6 @@ int pool_chain_groups(int bytes, int stride_e, int want)
     const int nw = v3c::strips_for(stride_e / 8);
     int g = 1;
     while (g * 2 <= want && g * 2 <= kChainMaxGroups && chain_waves(bytes, g * 2) >= nw) g *= 2;
-    // float rows are four coherent loads and four stores of eight bytes: with sixteen waves in each of two workgroups that
-    // costs more than the second workgroup's slots bring (720x480 YUV420PS: 7.8 k frames/s -> 6.1 k; 10.4 k with four, 15.2 k with eight)
-    if (bytes == 4 && g == 2) g = 1;
     return g;
 }
 
