@@ -29,6 +29,7 @@ struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool counted_live = false;  // this context is counted in g_live_contexts[device]
 
     int out_height = 0;  // vi.height after dh, SangNom2.cpp:284-285
     int stride_e = 0;    // SangNom2.cpp:287
@@ -157,6 +158,18 @@ struct PinnedRange {
 };
 static std::mutex g_pin_mutex;
 static std::vector<PinnedRange> g_pinned;
+// Devices on which this process has live contexts (index = device ordinal, value = contexts): what sn_unpin_host_buffer
+// has to wait for.  It used to walk every VISIBLE device, which in a multi-rank job that sees all GPUs created a primary
+// context on each of them and touched devices that belong to other ranks (round-3 advisor).
+static std::mutex g_live_mutex;
+static std::vector<int> g_live_contexts;
+static void live_context(int device, int delta)
+{
+    if (device < 0) return;
+    std::lock_guard<std::mutex> lk(g_live_mutex);
+    if ((size_t)device >= g_live_contexts.size()) g_live_contexts.resize((size_t)device + 1, 0);
+    g_live_contexts[(size_t)device] += delta;
+}
 
 // is the plane [p, p + pitch * (rows - 1) + row_bytes) inside pinned memory?
 static bool plane_is_pinned(const void* p, int pitch, int row_bytes, int rows)
@@ -300,6 +313,7 @@ void sn_destroy(sn_context* h)
     Context* c = reinterpret_cast<Context*>(h);
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->counted_live) sn::live_context(c->device, -1);
     // every stream that may still run kernels on this context's scratch drains first; only then is memory freed
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& g : c->ring)
@@ -548,6 +562,8 @@ int sn_create_with_policy(const sn_config* cfg, const sn_policy* policy, sn_cont
         sn_destroy(reinterpret_cast<sn_context*>(c));
         return rc;
     }
+    sn::live_context(c->device, +1);
+    c->counted_live = true;
     *out = reinterpret_cast<sn_context*>(c);
     return SN_OK;
 }
@@ -791,6 +807,7 @@ static int ensure_bands(Context* c)
 // call queues its copies from pageable host memory -- allocating in the middle of such a call (as the lazy
 // ensure_pool / ensure_bands of run_group would) puts hipMalloc / hipHostMalloc between the runtime's in-flight staging
 // of those copies and their completion.
+constexpr int SN_CHAIN_UNAVAILABLE = -1000;  // internal: run_chain could not get its ring, run_batch falls back
 static int chain_planes(const Context* c, int planes[3]);
 static int ensure_chain(Context* c, int pn, hipStream_t st);
 
@@ -806,8 +823,11 @@ static int prepare_small_launch_scratch(Context* c)
         if (pn > 0) {
             const int rc = ensure_pool(c);
             if (rc != SN_OK) return rc;
-            (void)ensure_chain(c, pn, c->stream);
-            SN_HIP(c, hipStreamSynchronize(c->stream));  // the ring's first user may be a ring slot's stream
+            const bool had_ring = c->chain_base != nullptr;
+            const int rc2 = ensure_chain(c, pn, c->stream);
+            if (rc2 != SN_OK && rc2 != SN_CHAIN_UNAVAILABLE) return rc2;  // (unavailable: the pass-by-pass path, no error pending)
+            // only when the ring has just been allocated and zeroed on c->stream: its first user may be a ring slot's stream
+            if (!had_ring && c->chain_base) SN_HIP(c, hipStreamSynchronize(c->stream));
         }
         return SN_OK;
     }
@@ -1150,7 +1170,6 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
 // k_smooth_u8_chain): stage 1 of all passes into a slot each, one stage-2 launch that keeps several passes in
 // flight, stage 3 of all passes.  The pool of slot 0 is where the chain starts and where its last pass's pool ends
 // up, so frames that come one at a time (and the pool's readers) carry on from there.
-constexpr int SN_CHAIN_UNAVAILABLE = -1000;  // internal: run_chain could not get its ring, run_batch falls back
 constexpr size_t kChainFlagBytes = (size_t)sn::kBuffers * sn::kChainMaxGroups * 32 * sizeof(uint32_t);
 #ifndef SN_CHAIN_DEFAULT_GROUPS
 #define SN_CHAIN_DEFAULT_GROUPS 8
@@ -1199,13 +1218,21 @@ static int ensure_chain(Context* c, int pn, hipStream_t st)
         c->chain_slots = -1;
         return SN_CHAIN_UNAVAILABLE;
     }
+    // the round counters and the status word of chains over several workgroups: without them the ring is no use (all or nothing)
+    if (hipMalloc(reinterpret_cast<void**>(&c->chain_flags), kChainFlagBytes) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->chain_status), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->chain_flags) (void)hipFree(c->chain_flags);
+        (void)hipFree(c->chain_base);
+        c->chain_flags = nullptr;
+        c->chain_status = nullptr;
+        c->chain_base = nullptr;
+        c->chain_slots = -1;
+        return SN_CHAIN_UNAVAILABLE;
+    }
+    *c->chain_status = 0;
     SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
     c->chain_origin = 0;
-    {
-        SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chain_flags), kChainFlagBytes));
-        SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->chain_status), sizeof(uint32_t), hipHostMallocDefault));
-        *c->chain_status = 0;
-    }
     return SN_OK;
 }
 
@@ -1374,17 +1401,19 @@ int sn_process_host(sn_context* h, const void* const src[3], const int32_t sp[3]
     if (rc != SN_OK) return rc;
     const int B = c->cfg.bytes_per_sample;
     for (int p = 0; p < c->nplanes(); ++p) {
-        if (!c->stage_src[p]) {
-            c->stage_src_pitch[p] = (c->plane_w(p) * B + 255) & ~255;
-            c->stage_dst_pitch[p] = c->stage_src_pitch[p];
-            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_src[p]),
-                                (size_t)c->stage_src_pitch[p] * c->plane_h_in(p)));
-            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_dst[p]),
-                                (size_t)c->stage_dst_pitch[p] * c->plane_h_out(p)));
+        // every resource is checked on its own: a call that failed half-way (SN_HIP returns) leaves the rest to the next call
+        c->stage_src_pitch[p] = (c->plane_w(p) * B + 255) & ~255;
+        c->stage_dst_pitch[p] = c->stage_src_pitch[p];
+        if (!c->stage_src[p])
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_src[p]), (size_t)c->stage_src_pitch[p] * c->plane_h_in(p)));
+        if (!c->stage_dst[p])
+            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->stage_dst[p]), (size_t)c->stage_dst_pitch[p] * c->plane_h_out(p)));
+        if (!c->sync_in[p])
             SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->sync_in[p]), (size_t)c->stage_src_pitch[p] * c->plane_h_in(p), hipHostMallocDefault));
+        if (!c->sync_out[p])
             SN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->sync_out[p]), (size_t)c->stage_dst_pitch[p] * (c->plane_h_out(p) / 2 + 1), hipHostMallocDefault));
-            for (int k = 0; k < kSyncChunks; ++k) SN_HIP(c, hipEventCreateWithFlags(&c->sync_back[p][k], hipEventDisableTiming));
-        }
+        for (int k = 0; k < kSyncChunks; ++k)
+            if (!c->sync_back[p][k]) SN_HIP(c, hipEventCreateWithFlags(&c->sync_back[p][k], hipEventDisableTiming));
     }
     ensure_copier(c);
     // Several planes: the copies go on streams of their own, so that plane p + 1 arrives and plane p - 1 leaves while plane
@@ -1752,27 +1781,35 @@ int sn_unpin_host_buffer(void* ptr)
     {
         std::lock_guard<std::mutex> lk(sn::g_pin_mutex);
         bool found = false;
-        for (size_t i = 0; i < sn::g_pinned.size(); ++i)
-            if (sn::g_pinned[i].lo == reinterpret_cast<uintptr_t>(ptr)) {
-                sn::g_pinned.erase(sn::g_pinned.begin() + (long)i);
-                found = true;
-                break;
-            }
+        for (size_t i = 0; i < sn::g_pinned.size() && !found; ++i) found = sn::g_pinned[i].lo == reinterpret_cast<uintptr_t>(ptr);
         if (!found) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "sn_unpin_host_buffer: not pinned through sn_pin_host_buffer");
     }
     // Nothing of this process may still be moving data through the mapping: the registry is process-wide and the
-    // buffers are registered portable, so a context on ANY device may have a transfer in flight on a stream of its own.
-    int ndev = 0, cur = 0;
-    if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess) {
-        for (int d = 0; d < ndev; ++d)
-            if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
-        (void)hipSetDevice(cur);
-    } else {
-        (void)hipGetLastError();
-        (void)hipDeviceSynchronize();
+    // buffers are registered portable, so a context on any device may have a transfer in flight on a stream of its own.
+    // Only devices that HAVE a context of this library are waited for (no primary context is created elsewhere).
+    std::vector<int> live;
+    {
+        std::lock_guard<std::mutex> lk(sn::g_live_mutex);
+        for (size_t d = 0; d < sn::g_live_contexts.size(); ++d)
+            if (sn::g_live_contexts[d] > 0) live.push_back((int)d);
     }
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (!have_cur) (void)hipGetLastError();
+    for (int d : live)
+        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    if (have_cur && !live.empty()) (void)hipSetDevice(cur);
     const hipError_t e = hipHostUnregister(ptr);
-    if (e != hipSuccess) return sn::fail(nullptr, SN_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {  // still registered, and still known to the library: the caller may try again
+        (void)hipGetLastError();
+        return sn::fail(nullptr, SN_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(sn::g_pin_mutex);
+    for (size_t i = 0; i < sn::g_pinned.size(); ++i)
+        if (sn::g_pinned[i].lo == reinterpret_cast<uintptr_t>(ptr)) {
+            sn::g_pinned.erase(sn::g_pinned.begin() + (long)i);
+            break;
+        }
     return SN_OK;
 }
 

@@ -4,38 +4,37 @@
 // Reference semantics: /root/reference/src/SangNom2.cpp:74-124 (prepareBuffers_c), :126-159
 // (processBuffers_c), :161-257 (finalizePlane_c), :361-391 (GetFrame's copies).
 //
-// The sweep (the 16-bit and float files share it):
-//   * one workgroup per (frame, plane); it sweeps the plane top to bottom because stage 2 is a vertical
-//     recurrence  O[r] = box7(O[r-1] + D[r] + D[r+1]) / 16 (mod 256);
-//   * a lane owns 8 consecutive pixels of every row and keeps, per cost buffer, only A[r] = O[r-1] + D[r]:
-//     S[r] = A[r] + D[r+1],  O[r] = (box7(S[r]) >> 4) & 255,  A[r+1] = O[r] + D[r+1];
-//   * the +-3 horizontal taps of the 7-tap box come from the neighbouring lanes with DPP wave_shr:1 / wave_shl:1
-//     folded into the adds (wavefront shuffles, no LDS);
-//   * the first / last GH lanes of a wave are "ghost" lanes: they recompute everything for the columns the
-//     neighbouring wave owns.  A ghost zone of G = GH * 8 pixels stays exact in its innermost 3 pixels for
-//     floor(G / 3) rows (the missing outer neighbour corrupts 3 more pixels per row), so the waves of a workgroup
-//     only meet every K = floor(G / 3) = 5 rows: the seam lanes publish their whole A state to an LDS mailbox, one
-//     s_barrier, the ghosts reload it.  The sweep is exact across wave seams (no speculation);
-//   * image edges clamp S to the first / last column (loadPixel on the line buffer, SangNom2.cpp:144-150):
-//     per-lane selects in the two edge waves only;
-//   * stage 3's priority ladder is a minimum over keys (cost << 4) | rank: smallest cost wins, ties go to the
-//     reference's priority order; the `minBuf > aaf` test is a tenth key with cost aaf + 1 and rank 0 that selects
-//     avg(c0, n0); the winner's rank bits drive a 4-level v_bfi tree over the nine tap sums.
-//
-// "Two virtual wavefronts per wave": tools/ubench_valu.hip shows that on gfx950 only plain 32-bit add / sub / and /
-// or / lshr issue at the full VALU rate; v_add3, v_sad, v_bfe, v_lshl_or, v_min, every DPP / SDWA form and every
-// v_pk_* are half rate.  All quantities of stage 1 and 2 fit 13 bits, so every 32-bit register here holds TWO
-// pixels from two different column strips -- bits 0..15 belong to virtual wavefront W (columns x), bits 16..31 to
-// virtual wavefront W + NW (columns x + NW * 480) -- and the pipeline runs on plain full-rate integer ops that
-// process both at once:
-//     S = A + D            one v_add_u32 for two pixels (no carry can cross: sums <= 5355)
-//     box: B[j+1] = B[j] - X[j-3] + X[j+4]   plain adds; window minus a member never borrows
-//     t = B & 0x0ff00ff0,  O = t >> 4,  key = t | rank,  A' = O + D
-//     SangNom value: ((4a + 5b - c + 2048) >> 3) & 0x00ff00ff   (2048 = 8 * 256 keeps it positive
-//                                                                 and does not change the result)
-//     |a - b| = max(a, b) - min(a, b) with v_pk_max_u16 / v_pk_min_u16 and one plain subtract
-// A DPP move of a packed register serves both virtual wavefronts (lane i-1 is the left neighbour in both strips).
-// Everything is integer; results are bit-exact to the pool path and to the opt=0 reference.
+// The sweep (the 16-bit and float files share its shape):
+//   * one workgroup per (frame, plane) sweeps the plane top to bottom, because stage 2 is a vertical recurrence
+//     O[r] = box7(O[r-1] + D[r] + D[r+1]) / 16 (mod 256);
+//   * a lane owns 8 consecutive pixels of every row IN EACH OF TWO COLUMN STRIPS: every quantity of stages 1 and 2 fits
+//     13 bits, so a 32-bit register holds two pixels -- bits 0..15 strip `wave`, bits 16..31 strip `wave + NW` -- and one
+//     instruction serves both.  Per cost buffer only A[r] = O[r-1] + D[r] is kept (8 registers), all nine in VGPRs;
+//   * per buffer and register the row body is nine instructions: U = x -sat y, V = y -sat x (v_pk_sub_u16 clamp; the cost
+//     |x - y| = U + V is never formed), S = A + U + V (v_add3), the sliding box B[j+1] = B[j] - X[j-3] + X[j+4] (two plain
+//     adds), key = (B & 0x0ff00ff0) | code (v_and_or), O = key >> 4 as a PACKED shift (the code falls off both halves),
+//     A' = O + U + V (v_add3), kmin = min(kmin, key) (v_pk_min_u16).  On gfx950 every packed, DPP and three-operand form
+//     issues in the same 4-cycle class and one such form in eight drags a whole stream there (profiles/r3_ubench_valu_*),
+//     so what counts is the NUMBER of instructions, and each of these forms replaces two to four simple ones;
+//   * the +-3 horizontal taps of the box come from the neighbouring lanes with DPP wave_shr:1 / wave_shl:1 (one move
+//     serves both strips).  Column 0 is lane 0 of the first strip and has no left neighbour: its DPP move keeps the `old`
+//     operand, S[0] -- loadPixel's clamp (SangNom2.cpp:25-34) for free; the last column takes one select per right-hand tap.
+//     The same box in every wave: no branch inside a buffer step;
+//   * the first / last GH lanes of a strip are ghost lanes that recompute the neighbouring strip's 16 columns.  A ghost
+//     zone stays exact in its innermost 3 pixels for floor(16 / 3) = 5 rows (the missing outer neighbour corrupts 3 more
+//     pixels per row), so the waves meet only every K = 5 rows: seam lanes publish their A state to an LDS mailbox, one
+//     s_barrier, the ghosts reload it.  Exact across seams, no speculation;
+//   * stage 3's ladder (SangNom2.cpp:204-249) is the minimum over keys (O << 4) | code -- smallest cost wins, ties follow
+//     the reference's priority order, the `minBuf > aaf` arm is a tenth key -- and what the winner selects is ONE byte
+//     of the line above and ONE of the line below (or the two SangNom values): byte permutes (v_perm_b32) whose selectors
+//     come from the winner's code through a byte table, then v_lerp_u8 = (a + b + 1) >> 1 on four pixels at once, on the
+//     lines as they lie in memory (RawLine: windows cut once per line with v_alignbyte, kept in LDS for its two rows);
+//   * memory: one buffer resource per frame plane, the row in the scalar offset, the column in a per-lane voffset that
+//     never changes; dead and ghost lanes carry an out-of-range voffset (loads read zero, stores are dropped): no branch
+//     around any memory operation.  One 16-byte load per strip and line, prefetched a row ahead.
+// Modes (sn_fused_v3_common.h): planes on their own (kPlain, kPadded), the pool-coupled sweeps of subsampled chroma
+// (kLumaSpill, kChroma, kChromaLast), and row bands (BAND) for launches of a few frames.  Everything is integer; results
+// are bit-exact to the pool path and to the opt=0 reference.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -180,23 +179,7 @@ __device__ __forceinline__ unsigned cost(const LineT& c, const LineT& n, int j)
     return pk_absdiff(x, y);
 }
 
-// Stage 3: a + b of the candidate that belongs to buffer BUF (SangNom2.cpp:214-249).
-template <int BUF>
-__device__ __forceinline__ unsigned tap_sum(const Line& c, const Line& n, int j)
-{
-    const int i = j + 3;
-    if constexpr (BUF == 0) return c.P[i - 3] + n.P[i + 3];
-    if constexpr (BUF == 1) return c.P[i - 2] + n.P[i + 2];
-    if constexpr (BUF == 2) return c.P[i - 1] + n.P[i + 1];
-    if constexpr (BUF == 3) return c.F(j) + n.B(j);
-    if constexpr (BUF == 4) return c.P[i] + n.P[i];
-    if constexpr (BUF == 5) return c.B(j) + n.F(j);
-    if constexpr (BUF == 6) return c.P[i + 1] + n.P[i - 1];
-    if constexpr (BUF == 7) return c.P[i + 2] + n.P[i - 2];
-    return c.P[i + 3] + n.P[i - 3];
-}
-
-// ---- Stage 3 in the byte domain (planes on their own) ---------------------------------------------------------------
+// ---- Stage 3 in the byte domain ---------------------------------------------------------------
 // The ladder's winner picks, per pixel, ONE byte of the upper line and ONE byte of the lower line (SangNom2.cpp:214-249:
 // c(k) and n(-k) for k = -3 .. 3, or the two SangNom values), and the result is their rounded average.  In the packed
 // pair layout that is nine tap sums and an eight-select tree per register (31 instructions per pixel pair).  On the
@@ -260,15 +243,13 @@ __device__ __forceinline__ unsigned interpolate4(const RawLine& c, const RawLine
     return __builtin_amdgcn_lerp(cc, nn, 0x01010101u);  // (a + b + 1) >> 1 per byte, SangNom2.cpp:48-52
 }
 
-// rank of buffer BUF in the reference's ladder: P4, P5, P3, P6, P2, P7, P1, P8, P0 -> 1..9
-// ... -> the codes of the byte-domain stage 3 (see RawLine) where that runs
-__host__ __device__ constexpr bool raw_stage3(int) { return true; }
+// the code of buffer BUF in the ladder keys (see RawLine): the reference's order P4, P5, P3, P6, P2, P7, P1, P8, P0
+// (SangNom2.cpp:214-249) as 0, 1, 2, 3, 4, 5, 6, 7, 12 -- smaller wins a tie
 template <int BUF, int MODE>
 constexpr unsigned rank_of()
 {
-    constexpr unsigned r[9] = {9, 7, 5, 3, 1, 2, 4, 6, 8};
     constexpr unsigned code[9] = {12, 6, 4, 2, 0, 1, 3, 5, 7};
-    return (raw_stage3(MODE) ? code[BUF] : r[BUF]) * 0x00010001u;
+    return code[BUF] * 0x00010001u;
 }
 
 // The 7-tap box over S with the line buffer's clamps (SangNom2.cpp:144-150), the same instructions in every wave:
@@ -469,13 +450,11 @@ struct Out {
     uint32_t lo[2], hi[2];  // 8 interpolated bytes of each strip
 };
 
-// The line above the pair being interpolated (c = K[r-1]) is needed only by stage 3, after the
-// nine buffer steps.  It is parked in LDS while they run (each lane reads back exactly the 24 dwords
-// it wrote itself, so no barrier is involved) -- that keeps the kernel inside 256 VGPRs without
-// scratch spills, whose reloads would park a wave that has only one partner on its SIMD.
-// Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others in LDS between their steps.
-// The pool-coupled modes hold a few more values per buffer step (the smoothed row to store, the stale row
-// in flight), so they keep fewer buffers in registers: anything that spills is far more expensive.
+// Stage 3 needs the line above and the line below the interpolated one as RawLines; a line is cut into that form once,
+// when it is unpacked, and parked in LDS for the two rows that use it (a ring of three lines, each lane reads back
+// exactly what it wrote itself, so no barrier is involved).
+// Buffers 0 .. reg_buffers(MODE)-1 keep their A state in VGPRs, the others (none since round 3, every mode holds all nine;
+// the SN_*_RB knobs remain for A/B builds) in LDS between their steps.
 #ifndef SN_PLAIN_RB
 #define SN_PLAIN_RB 9
 #endif
@@ -499,7 +478,7 @@ struct Parked {  // views into the workgroup's dynamic LDS, sized by its thread 
     uint4* v;    // [6][NT]: the parked line; byte-domain stage 3: [3 lines][5][NT], line k in slot k % 3 (RawLine)
     uint4* a;    // [kBuffers - RB][2][NT]: A of the LDS-resident buffers, thread-private slots
 };
-__host__ __device__ constexpr int parked_line_slots(int mode) { return raw_stage3(mode) ? 15 : 6; }
+__host__ __device__ constexpr int parked_line_slots(int) { return 15; }  // three lines (RawLine) x five uint4 per thread
 
 template <int NT, int RB>
 __device__ __forceinline__ void load_A(const Parked<NT, RB>& pk, int tid, int b, unsigned (&A)[PXL])
@@ -515,19 +494,6 @@ __device__ __forceinline__ void store_A(const Parked<NT, RB>& pk, int tid, int b
     pk.a[((b - RB) * 2 + 1) * pk.nthreads + tid] = make_uint4(A[4], A[5], A[6], A[7]);
 }
 
-template <int NT, int RB>
-__device__ __forceinline__ void park_line(const Parked<NT, RB>& pk, int tid, const Line& L)
-{
-    pk.v[0 * pk.nthreads + tid] = make_uint4(L.P[0], L.P[1], L.P[2], L.P[3]);
-    pk.v[1 * pk.nthreads + tid] = make_uint4(L.P[4], L.P[5], L.P[6], L.P[7]);
-    pk.v[2 * pk.nthreads + tid] = make_uint4(L.P[8], L.P[9], L.P[10], L.P[11]);
-    pk.v[3 * pk.nthreads + tid] = make_uint4(L.P[12], L.P[13], L.FB[0], L.FB[1]);
-    pk.v[4 * pk.nthreads + tid] = make_uint4(L.FB[2], L.FB[3], L.FB[4], L.FB[5]);
-    pk.v[5 * pk.nthreads + tid] = make_uint4(L.FB[6], L.FB[7], 0u, 0u);
-}
-
-template <int NT, int RB>
-__device__ __forceinline__ void park_line(const Parked<NT, RB>&, int, const WideLine&) {}  // never called: stage 3 in the byte domain parks a RawLine
 template <int NT, int RB>
 __device__ __forceinline__ void park_raw(const Parked<NT, RB>& pk, int tid, int slot, const RawLine& R)
 {
@@ -548,18 +514,6 @@ __device__ __forceinline__ void unpark_raw(const Parked<NT, RB>& pk, int tid, in
     R.W[1][2] = c.x; R.W[1][3] = c.y; R.W[1][4] = c.z; R.W[1][5] = c.w;
     R.F[0][0] = d.x; R.F[0][1] = d.y; R.B[0][0] = d.z; R.B[0][1] = d.w;
     R.F[1][0] = e.x; R.F[1][1] = e.y; R.B[1][0] = e.z; R.B[1][1] = e.w;
-}
-
-template <int NT, int RB>
-__device__ __forceinline__ void unpark_line(const Parked<NT, RB>& pk, int tid, Line& L)
-{
-    const uint4 a = pk.v[0 * pk.nthreads + tid], b = pk.v[1 * pk.nthreads + tid], c = pk.v[2 * pk.nthreads + tid], d = pk.v[3 * pk.nthreads + tid], e = pk.v[4 * pk.nthreads + tid], f = pk.v[5 * pk.nthreads + tid];
-    L.P[0] = a.x; L.P[1] = a.y; L.P[2] = a.z; L.P[3] = a.w;
-    L.P[4] = b.x; L.P[5] = b.y; L.P[6] = b.z; L.P[7] = b.w;
-    L.P[8] = c.x; L.P[9] = c.y; L.P[10] = c.z; L.P[11] = c.w;
-    L.P[12] = d.x; L.P[13] = d.y; L.FB[0] = d.z; L.FB[1] = d.w;
-    L.FB[2] = e.x; L.FB[3] = e.y; L.FB[4] = e.z; L.FB[5] = e.w;
-    L.FB[6] = f.x; L.FB[7] = f.y;
 }
 
 // S3: the row has an interpolated line (stage 3); kChroma sweeps one extra row without one.
@@ -611,59 +565,20 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
 
     Out o{};
     if constexpr (!S3) return o;
-    if constexpr (raw_stage3(MODE)) {
-        // rank codes of the eight winners of each strip, four to a dword in pixel order (RawLine has the rest)
-        RawLine c, nr;
-        unpark_raw(pk, tid, rc.slot_c, c);
-        unpark_raw(pk, tid, rc.slot_n, nr);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const unsigned t01 = __builtin_amdgcn_perm(kmin[4 * g + 1], kmin[4 * g + 0], 0x06020400u);  // [lo0 lo1 hi0 hi1]
-            const unsigned t23 = __builtin_amdgcn_perm(kmin[4 * g + 3], kmin[4 * g + 2], 0x06020400u);
-            const unsigned lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) & 0x0f0f0f0fu;
-            const unsigned hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u) & 0x0f0f0f0fu;
-            o.lo[g] = interpolate4(c, nr, 0, g, lo);
-            o.hi[g] = interpolate4(c, nr, 1, g, hi);
-        }
-        return o;
-    }
-    else {
-    // winner's rank -> tap sum -> average
-    Line c;
-    unpark_line(pk, tid, c);
-    unsigned v[PXL];
-#pragma unroll
-    for (int j = 0; j < PXL; ++j) {
-        const unsigned wk = kmin[j];
-        // rank bit k of each half -> a mask over that half: packed shift left to the sign bit, packed arithmetic
-        // shift back (two instructions per mask)
-        // (not in the pool-coupled modes: they sit at the register limit, and there the plain form allocates better)
-        const unsigned m0 = has_pools(MODE) ? (wk & 0x00010001u) * 0xffffu : pk_bit_mask<0>(wk);
-        const unsigned m1 = has_pools(MODE) ? ((wk >> 1) & 0x00010001u) * 0xffffu : pk_bit_mask<1>(wk);
-        const unsigned m2 = has_pools(MODE) ? ((wk >> 2) & 0x00010001u) * 0xffffu : pk_bit_mask<2>(wk);
-        const unsigned m3 = has_pools(MODE) ? ((wk >> 3) & 0x00010001u) * 0xffffu : pk_bit_mask<3>(wk);
-        // ranks: 0,1 -> P4; 2 -> P5; 3 -> P3; 4 -> P6; 5 -> P2; 6 -> P7; 7 -> P1; 8 -> P8; 9 -> P0
-        const unsigned a01 = tap_sum<4>(c, n, j);
-        const unsigned a23 = bfi(m0, tap_sum<3>(c, n, j), tap_sum<5>(c, n, j));
-        const unsigned a45 = bfi(m0, tap_sum<2>(c, n, j), tap_sum<6>(c, n, j));
-        const unsigned a67 = bfi(m0, tap_sum<1>(c, n, j), tap_sum<7>(c, n, j));
-        const unsigned a89 = bfi(m0, tap_sum<0>(c, n, j), tap_sum<8>(c, n, j));
-        const unsigned b0 = bfi(m1, a23, a01);
-        const unsigned b1 = bfi(m1, a67, a45);
-        const unsigned c0 = bfi(m2, b1, b0);
-        const unsigned r = bfi(m3, a89, c0);
-        v[j] = has_pools(MODE) ? (((r + 0x00010001u) >> 1) & kByte) : pk_avg_from_sum(r);  // (a + b + 1) >> 1 in both halves
-    }
-    // v[j] = lo-strip byte | hi-strip byte << 16  ->  four bytes per dword and strip
+    // rank codes of the eight winners of each strip, four to a dword in pixel order (RawLine has the rest)
+    RawLine c, nr;
+    unpark_raw(pk, tid, rc.slot_c, c);
+    unpark_raw(pk, tid, rc.slot_n, nr);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const unsigned t01 = __builtin_amdgcn_perm(v[4 * g + 1], v[4 * g + 0], 0x06020400u);  // [v0.b0, v1.b0, v0.b2, v1.b2]
-        const unsigned t23 = __builtin_amdgcn_perm(v[4 * g + 3], v[4 * g + 2], 0x06020400u);
-        o.lo[g] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);  // [t01.b0, t01.b1, t23.b0, t23.b1]
-        o.hi[g] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);  // [t01.b2, t01.b3, t23.b2, t23.b3]
+        const unsigned t01 = __builtin_amdgcn_perm(kmin[4 * g + 1], kmin[4 * g + 0], 0x06020400u);  // [lo0 lo1 hi0 hi1]
+        const unsigned t23 = __builtin_amdgcn_perm(kmin[4 * g + 3], kmin[4 * g + 2], 0x06020400u);
+        const unsigned lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) & 0x0f0f0f0fu;
+        const unsigned hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u) & 0x0f0f0f0fu;
+        o.lo[g] = interpolate4(c, nr, 0, g, lo);
+        o.hi[g] = interpolate4(c, nr, 1, g, hi);
     }
     return o;
-    }
 }
 
 // LDS mailbox, receiver-ready: word [refresh parity][wave W][side][slot][i] is what ghost lane
@@ -865,15 +780,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         const Raw f0 = clamp_edges(q0, role), f1 = clamp_edges(q1, role);
         unpack(L0, f0);
         unpack(L1, f1);
-        if constexpr (raw_stage3(MODE)) {
-            RawLine R;
-            make_raw(R, f0, L0);
-            park_raw(parked, tid, (r0 - 1) % 3, R);  // K[r0 - 1]: c of row r0
-            make_raw(R, f1, L1);
-            park_raw(parked, tid, r0 % 3, R);        // K[r0]: n of row r0
-        } else {
-            park_line(parked, tid, L0);  // c of row 1
-        }
+        RawLine R;
+        make_raw(R, f0, L0);
+        park_raw(parked, tid, (r0 - 1) % 3, R);  // K[r0 - 1]: c of row r0
+        make_raw(R, f1, L1);
+        park_raw(parked, tid, r0 % 3, R);        // K[r0]: n of row r0
     }
 
     // A[1] = O[0] + P[1] = P[1] (pool row 0 is never written: zero); P[1] = stage-1 costs of the first
@@ -946,11 +857,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         if constexpr (HAS_NEXT) {
             const Raw fq = clamp_edges(qn, role);  // waits for the line prefetched one row ago
             unpack(nn, fq);
-            if constexpr (raw_stage3(MODE)) {
-                RawLine R;
-                make_raw(R, fq, nn);
-                park_raw(parked, tid, (r + 1) % 3, R);  // K[r + 1]: n of the next row, c of the one after
-            }
+            RawLine R;
+            make_raw(R, fq, nn);
+            park_raw(parked, tid, (r + 1) % 3, R);  // K[r + 1]: n of the next row, c of the one after
             keep(dst_keep, qn, !BAND || (r + 1 >= ra && r < rb));
             dst_keep += dst_step;
         }
@@ -1000,7 +909,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         const Out o = row_step<MODE, HAS_NEXT, S3, STORE>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S3) put(out_row, o);  // stored at once: nothing is carried into the next row
         out_row += dst_step;
-        if constexpr (HAS_NEXT && !raw_stage3(MODE)) park_line(parked, tid, n);  // n is the next row's c
         if (r < sweep) {
             if (r % K == 0) {
                 if constexpr (mailbox_copies(MODE) == 1) __syncthreads();  // the previous refresh has been taken out

@@ -424,8 +424,21 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs po
 // ---- chains over several workgroups per buffer (see k_smooth_u8_chain): the pieces the three sample types share ----
 constexpr int kChainSpinLimit = 1 << 20;  // x (s_sleep 8 + a load from memory): two seconds and more
 
+// Release side of the hand-off between workgroups: EVERY wave drains its own sc1 stores (s_waitcnt vmcnt(0): a store
+// counts down when memory has acknowledged it at the scope of its sc bits) before the barrier that precedes the
+// publish of the round counter.  The barrier alone does not do it: __syncthreads() is a workgroup-scope fence, which on
+// gfx950 outside tgsplit mode waits for LDS traffic only, and the compiler's own s_waitcnt before s_barrier covered the
+// stores in the 8-bit kernel by accident and left vmcnt(1..2) in the 16-bit / float ones (round-3 advisor, disassembly).
+// Data and flag travel to different L2 channels, so without the drain a consumer could see the counter before the rows.
+// tests/test_capi_cpu.py checks the disassembly for this instruction in front of every s_barrier of the *_chain<true> loops.
+__device__ __forceinline__ void chain_release_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), expcnt and lgkmcnt left alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14)
+    __syncthreads();
+}
+
 // The round counters of a buffer's workgroups.  enter(), right after the barrier that opens round `round`: the workgroup
-// publishes "rounds < round are complete" (the barrier waited for its stores), and the waves of its first slot make sure
+// publishes "rounds < round are complete" (chain_release_barrier() drained every wave's stores), and the waves of its first slot make sure
 // the workgroup before it has completed round `round - 1 - slack` -- with the value they fetched while the round before
 // ran if that is enough (in step it is: the schedule starts a workgroup's slots `slack` rounds late), polling otherwise,
 // for two seconds at most: then the workgroup gives up waiting for good and raises the host-visible status word.
@@ -505,7 +518,7 @@ constexpr int kChain8Threads = SN_CHAIN8_THREADS;
 //     across the XCDs without cache maintenance.  Agent-scope FENCES cost 7 - 20 us per round here and the more the more
 //     workgroups issue them, the sc1 accesses 1.3 us when the reader sits waiting for them:
 //     tools/experiments/ubench_xwg_sync.hip, profiles/r3_chain.md);
-//   * a workgroup publishes "rounds completed" after its barrier (which waits for its stores), and the waves of its
+//   * a workgroup publishes "rounds completed" after chain_release_barrier() (every wave drains its stores, then the barrier), and the waves of its
 //     first slot start round R only when the workgroup before them has completed round R - 1 - slack.  The schedule
 //     starts workgroup g's slots g * slack rounds late, so in step that counter is `slack` rounds old news: the waves look
 //     at the value they fetched while the round before ran (a fresh poll is a trip to memory on the round's critical path,
@@ -515,7 +528,7 @@ constexpr int kChain8Threads = SN_CHAIN8_THREADS;
 //   * a pass's first rows come from memory as well: they are fetched at the start of the pass's first round and taken
 //     into the registers at its end (LATE_PRIME), not waited for on the spot.
 // 720x480 YUV420P8, 512 frames per launch: 23.1 k frames/s with one workgroup per buffer, 28.4 k with two, 31.5 k with
-// four (the default: 36 CUs), 32.9 k with eight.  Tried and dropped: fetching a round's rows all at its start into a
+// four (36 CUs), 32.9 k with eight (the default: kChainDefaultGroups, sn_api.hip).  Tried and dropped: fetching a round's rows all at its start into a
 // second ring (slower), waiting only for the stores of a round's first two rows at the barrier (no change).
 #ifdef SN_CHAIN_TIMING
 // -DSN_CHAIN_TIMING (tools/chain_timing.py): shader-clock cycles the waves that had rows spent, summed over them, in
@@ -691,7 +704,8 @@ __global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, Chai
 #ifdef SN_CHAIN_TIMING
         last_ = __builtin_amdgcn_s_memtime();
 #endif
-        __syncthreads();  // (waits for this wave's stores and loads, then for everybody's)
+        if constexpr (GROUPED) chain_release_barrier();  // this wave's stores have landed, then everybody's
+        else __syncthreads();  // (one workgroup: same CU, the barrier orders LDS and the L1-coherent rows)
         SN_TICK(0);
         if constexpr (GROUPED) sync.enter(round, pair == 0, tid);
         SN_TICK(1);
@@ -914,7 +928,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
     if constexpr (GROUPED) sync.init(ch, b, grp);
     const int gslot = grp * lanes + ps;  // the slot among all of the buffer's
     for (int round = 0; round < total; ++round) {
-        __syncthreads();
+        if constexpr (GROUPED) chain_release_barrier();
+        else __syncthreads();
         if constexpr (GROUPED) sync.enter(round, ps == 0, tid);
         const int rel = round - (gslot * kChainLag + grp * slack);
         if (rel < 0) continue;
@@ -1069,7 +1084,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
     if constexpr (GROUPED) sync.init(ch, b, grp);
     const int gslot = grp * lanes + ps;  // the slot among all of the buffer's
     for (int round = 0; round < total; ++round) {
-        __syncthreads();
+        if constexpr (GROUPED) chain_release_barrier();
+        else __syncthreads();
         if constexpr (GROUPED) sync.enter(round, ps == 0, tid);
         const int rel = round - (gslot * kChainLag + grp * slack);
         if (rel < 0) continue;

@@ -225,6 +225,30 @@ def cpu_baseline(fmt, w, h, kw, seconds_target=7.0):
     return rec
 
 
+def verify_against_pool_path(torch, SangNom2, clip, dev_index, stream, kw, src, dst, batch):
+    """Frames 0 and batch - 1 of `dst` (written by the timed launches) against a mode="pool" context fed the same source
+    frames.  A history-free clip's frame does not depend on its neighbours, so a fresh pool-path instance reproduces any
+    frame of the batch on its own; a history-carrying clip (width % 32 != 0, chroma-only) is replayed from frame 0, so
+    there only frame 0 and -- when the batch is small enough to replay -- the last frame are compared."""
+    frames = sorted({0, batch - 1})
+    t0 = time.perf_counter()
+    checked, equal, history_free = [], True, True
+    with SangNom2(clip, device=dev_index, max_batch=1, mode="pool", stream=stream.cuda_stream, **kw) as ref:
+        history_free = bool(ref.info().history_free)
+        for f in frames:
+            if f > 0 and not history_free:
+                continue  # (its state depends on every frame before it: not replayed for a large batch)
+            one_s = [t[f:f + 1] for t in src]
+            one_d = [torch.empty_like(t[f:f + 1]) for t in dst]
+            ref.process_batch(one_s, one_d)
+            torch.cuda.synchronize()
+            same = all(bool(torch.equal(a[0], b[f])) for a, b in zip(one_d, dst))
+            checked.append(f)
+            equal = equal and same
+    return {"ok": equal, "frames": len(checked), "which": checked, "against": "pool path (mode=pool context, one frame per launch)",
+            "planes": len(dst), "seconds": round(time.perf_counter() - t0, 3)}
+
+
 def spawn_ranks(args) -> int:
     """`--gpus N` without a launcher: run the N ranks as children of this process, which has not touched the
     GPU (no torch.cuda call, no HIP library loaded) and never will -- a process that has initialised the GPU
@@ -333,8 +357,12 @@ def main():
             dist.barrier()
 
     torch.cuda.synchronize(dev)  # inputs were generated on the default stream
+    gpu_t0 = time.perf_counter()
+    wev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    wev[0].record(stream)
     for _ in range(args.warmup):
         flt.process_batch(src, dst)
+    wev[1].record(stream)
     torch.cuda.synchronize(dev)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -358,6 +386,18 @@ def main():
     dev_ms = sorted(a.elapsed_time(b) for a, b in ev)
     launch_ms = sum(dev_ms) / len(dev_ms)
     info = flt.info()
+    gpu_active_ms = sum(dev_ms) + (wev[0].elapsed_time(wev[1]) if args.warmup else 0.0)
+
+    # The line vouches for its own output (outside the timed region): the first and the last frame of the batch the
+    # timed launches wrote are recomputed by a SECOND context on the three-kernel pool path over the HBM-resident pool
+    # (sn_pool_kernels.hip: other kernels, other data layout, the semantic reference of the sweeps on the GPU) and must
+    # be byte-equal; a mismatch is an error, not a note.  What both compute: /root/reference/src/SangNom2.cpp:332-397.
+    verified = None
+    if rank == 0:
+        verified = verify_against_pool_path(torch, SangNom2, clip, dev_index, stream, kw, src, dst, batch)
+        if not verified["ok"]:
+            print(json.dumps({"error": "bench.py: the timed launches' output differs from the pool path", "verified": verified}), flush=True)
+            raise SystemExit(3)
 
     joined = dist.get_world_size() if launched else 1  # ranks that really took part
     # every rank's own figures, so that a straggler shows in the line (the aggregate uses the slowest rank's time)
@@ -405,6 +445,7 @@ def main():
                        "frames_per_step_per_gpu": batch, "frame": f"{w}x{out_h} {fmt}",
                        "path": "fused" if info.fused_frames > 0 else "pool", "sharding": "frames, no collective"},
             "frames_per_s": round(frames_total / elapsed, 1),
+            "verified": verified,
             "roofline": {"bound": "valu-issue", "roofline_reported": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -428,6 +469,11 @@ def main():
                 li = lat.info()
                 out["single_frame"] = {"ms": round(a0.elapsed_time(a1) / 50, 4), "banded": li.banded_frames > 0,
                                        "band_fallbacks": int(li.band_fallbacks), "launches": 50}
+        # device time of the launches this process queued (HIP events: warm-up + timed steps; the single-frame and
+        # verification legs add a few ms), and the wall-clock window they fell in -- the CPU leg below keeps the GPU
+        # idle for ~10 s, which is what a utilisation sampler sees most of the run
+        out["gpu_active_s"] = round(gpu_active_ms / 1e3, 4)
+        out["gpu_window_s"] = round(time.perf_counter() - gpu_t0, 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fmt, w, h, kw)
         print(json.dumps(out), flush=True)

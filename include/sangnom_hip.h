@@ -208,7 +208,14 @@ int sn_collect_host(sn_context* ctx, int32_t slot, void* const dst[3], const int
  * memory -- the transfer reads the caller's memory asynchronously -- so such a plane must stay valid and UNCHANGED
  * until its slot has been collected (a host that recycles frame buffers keeps the frame referenced until then, as
  * host/sangnom2_filter.hpp does).  Unpinned source planes are copied into the slot's staging before the call
- * returns, as ever.  sn_unpin_host_buffer waits for every device's outstanding work before it unregisters. */
+ * returns, as ever.  sn_unpin_host_buffer waits for the outstanding work of every device this library has a context on
+ * before it unregisters; when the runtime refuses to unregister, the range stays pinned and known (SN_ERR_HIP).
+ * EXPERIMENTAL on ROCm 7.2 / gfx950: a process that has registered and later UNREGISTERED host memory was seen to abort,
+ * about once in twenty young processes, inside a LATER asynchronous copy from or to PAGEABLE memory -- the runtime's
+ * own pin-on-the-fly path, torch's transfers included; never inside this library, which stages every pageable plane
+ * through its own pinned buffers (profiles/r3_page_fault.md, tools/repro_pageable_after_unpin.py).  A host that uses
+ * these two entry points should (a) pin its frame arenas once and unpin them only at shutdown, and (b) keep its other
+ * device transfers on pinned memory as well.  Without them nothing is registered and the hazard does not arise. */
 int sn_pin_host_buffer(void* ptr, size_t bytes);
 int sn_unpin_host_buffer(void* ptr);
 int sn_submit_host_to(sn_context* ctx, const void* const src[3], const int32_t src_pitch[3], void* const dst[3],

@@ -123,3 +123,16 @@ def test_header_is_plain_c_and_every_entry_point_links(tmp_path):
                            "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_chain_hand_off_between_workgroups_drains_its_stores_before_the_barrier():
+    """Release side of the chains over several workgroups per buffer (sn_pool_kernels.hip, chain_release_barrier): in
+    the gfx950 ISA of every k_smooth_*_chain<true> kernel an `s_waitcnt vmcnt(0)` stands in front of the round loop's
+    s_barrier, so that a workgroup's rows have landed before its round counter is published.  Checked in the ISA because
+    it is the compiler that places (or drops) the wait: round 3's build had it in the 8-bit kernel by accident only."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_chain_release.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert r.stdout.count("0 without a preceding s_waitcnt vmcnt(0)") == 3, r.stdout

@@ -13,7 +13,7 @@ import pytest
 from avisynth_sangnom2_amd import ClipFormat, SangNom, SangNom2, SangNomAA, SangNomAAHost, SangNomError, clip_format, synth
 from oracle.oracle import Oracle
 from oracle.sangnom_numpy import NumpySangNom
-from tests.util import describe_diff, make_frames, oracle_cfg, same
+from tests.util import describe_diff, make_frames, oracle_cfg, same, to_host
 
 
 @pytest.fixture(autouse=True)
@@ -130,7 +130,7 @@ def test_device_batch_matches_oracle(hip_lib):
             ora = Oracle(oracle_cfg(clip, **kw))  # fresh instance per frame: history-free
             want = ora.process(frames[f], parity=parity[f])
             for p in range(3):
-                assert same(want[p], dst[p][f].cpu().numpy()), f"frame {f} plane {p}"
+                assert same(want[p], to_host(dst[p][f])), f"frame {f} plane {p}"
 
 
 def test_device_batch_history_carrying(hip_lib):
@@ -149,7 +149,7 @@ def test_device_batch_history_carrying(hip_lib):
         flt.synchronize()
         for f in range(N):
             want = ora.process(frames[f])
-            assert same(want[0], dst[0][f].cpu().numpy()), f"frame {f}"
+            assert same(want[0], to_host(dst[0][f])), f"frame {f}"
 
 
 def test_validation_errors_are_the_references(hip_lib):
@@ -303,9 +303,9 @@ def test_fused_equals_pool_at_full_size(hip_lib):
             torch.cuda.synchronize()
             flt.process_batch(src, dst, parity=[1, 1, 1])
             flt.synchronize()
-            outs[mode] = dst[0].cpu().numpy()
+            outs[mode] = to_host(dst[0])
     assert np.array_equal(outs["fused"], outs["pool"])
-    want = Oracle(oracle_cfg(clip)).process([src[0][2].cpu().numpy()])
+    want = Oracle(oracle_cfg(clip)).process([to_host(src[0][2])])
     assert same(want[0], outs["fused"][2])
 
 
@@ -340,10 +340,10 @@ def test_full_size_fused_equals_pool_and_oracle(hip_lib, name, fmt, w, h, kw, N)
             torch.cuda.synchronize()
             flt.process_batch(src, dst)
             flt.synchronize()
-            outs[mode] = [d.cpu().numpy() for d in dst]
+            outs[mode] = [to_host(d) for d in dst]
     for p in range(clip.planes):
         assert np.array_equal(outs["fused"][p], outs["pool"][p]), f"{name}: plane {p} differs between fused and pool"
-    want = Oracle(oracle_cfg(clip, **kw)).process([s[0].cpu().numpy() for s in src])
+    want = Oracle(oracle_cfg(clip, **kw)).process([to_host(s[0]) for s in src])
     for p in range(clip.planes):
         assert same(want[p], outs["fused"][p][0]), f"{name}: plane {p} differs from the oracle"
 
@@ -446,7 +446,7 @@ def test_pool_stage2_kernels_match_oracle(hip_lib, fmt, w):
             flt.process_batch([src[0][:n]], [dst[0][:n]], parity=[1] * n)
             flt.synchronize()
             for f in range(n):
-                got = dst[0][f].cpu().numpy().view(clip.dtype)
+                got = to_host(dst[0][f]).view(clip.dtype)
                 assert same(want[f][0], got), f"{fmt} {w} launch of {n}, frame {f}: " + describe_diff(want[f][0], got)
 
 
@@ -494,7 +494,7 @@ def test_history_carrying_chain_matches_oracle(hip_lib, monkeypatch, fmt, w, h, 
             for f in range(N):
                 want = ora.process(frames[f], parity=parity[f])
                 for p in range(clip.planes):
-                    got = dst[p][f].cpu().numpy().view(clip.dtype)
+                    got = to_host(dst[p][f]).view(clip.dtype)
                     assert same(want[p], got), f"round {rnd} frame {f} plane {p}: " + describe_diff(want[p], got)
         assert 2 * (N - 1) <= flt.info().chained_frames <= 2 * N  # (the field only moves the lines when order = 0)
         # a frame on its own carries on from the chain's last pool, and the pool itself is the reference's
@@ -547,7 +547,7 @@ def test_chain_over_several_workgroups_per_buffer_matches_oracle(hip_lib, monkey
             for f in range(N):
                 want = ora.process(frames[f])
                 for p in range(clip.planes):
-                    got = dst[p][f].cpu().numpy().view(clip.dtype)
+                    got = to_host(dst[p][f]).view(clip.dtype)
                     assert same(want[p], got), f"{groups} workgroups, round {rnd} frame {f} plane {p}: " + describe_diff(want[p], got)
         assert flt.info().chained_frames == 2 * N
         assert np.array_equal(ora.pool(), flt.read_pool(0))
@@ -625,7 +625,7 @@ def test_chain_can_be_switched_off(hip_lib, monkeypatch):
         flt.synchronize()
         assert flt.info().chained_frames == 0
         for f in range(4):
-            assert same(ora.process(frames[f])[0], dst[0][f].cpu().numpy())
+            assert same(ora.process(frames[f])[0], to_host(dst[0][f]))
 
 
 @pytest.mark.parametrize("fmt,mode", [("YUV420P8", "fused"), ("YUV420P16", "fused"), ("YUV420P8", "pool"), ("Y16", "pool")])
@@ -652,7 +652,7 @@ def test_batch_larger_than_the_scratch_budget_runs_in_chunks(hip_lib, monkeypatc
     for f in range(N):
         want = Oracle(oracle_cfg(clip, **kw)).process(frames[f])
         for p in range(clip.planes):
-            got = dst[p][f].cpu().numpy().view(clip.dtype)
+            got = to_host(dst[p][f]).view(clip.dtype)
             assert same(want[p], got), f"frame {f} plane {p}: " + describe_diff(want[p], got)
 
 
@@ -767,7 +767,7 @@ def test_fresh_pool_equals_a_new_instance_per_frame_and_plane(hip_lib, fmt, w, h
             yclip = ClipFormat(width=w >> (clip.subw if p else 0), height=h >> (clip.subh if p else 0), bytes=clip.bytes, bits=clip.bits)
             ora = Oracle(oracle_cfg(yclip, order=kw.get("order", 1), aa=kw.get("aa", 48) if p == 0 else kw.get("aac", 0), dh=kw.get("dh", False)))
             want = ora.process([frames[f][p]], parity=parity[f])[0]
-            got = dst[p][f].cpu().numpy().view(clip.dtype)
+            got = to_host(dst[p][f]).view(clip.dtype)
             assert same(want, got), f"frame {f} plane {p}: " + describe_diff(want, got)
             if f == 1:
                 assert same(want, host_way[p]), f"host path, plane {p}"
@@ -787,7 +787,7 @@ def test_turn_device_is_avisynths_turnright_turnleft(hip_lib, fmt, w, h):
             torch.cuda.synchronize()
             flt.turn(src, dst, direction)
             flt.synchronize()
-            assert np.array_equal(dst.cpu().numpy().view(clip.dtype), np.rot90(a, k=k, axes=(1, 2)))
+            assert np.array_equal(to_host(dst).view(clip.dtype), np.rot90(a, k=k, axes=(1, 2)))
 
 
 AA_CASES = [("Y8", 128, 64, dict(aa=48)), ("YUV420P8", 128, 64, dict(aa=48, aac=48)), ("Y16", 96, 64, dict(aa=30, order=2)),
@@ -832,7 +832,7 @@ def test_anti_aliasing_idiom_on_the_device(hip_lib, fmt, w, h, kw):
         aa.synchronize()
     for f in range(N):
         for p in range(clip.planes):
-            got = dst[p][f].cpu().numpy().view(clip.dtype)
+            got = to_host(dst[p][f]).view(clip.dtype)
             assert same(want[f][p], got), f"frame {f} plane {p}: " + describe_diff(want[f][p], got)
 
 
@@ -928,7 +928,7 @@ def test_legacy_sangnom_wrapper_and_single_frame_device_entry(hip_lib):
         flt.get_frame_device(src, dst)
         flt.synchronize()
         for p in range(3):
-            assert same(want[p], dst[p].cpu().numpy()), f"device frame plane {p}"
+            assert same(want[p], to_host(dst[p])), f"device frame plane {p}"
 
 
 @pytest.mark.small_launch_policy
@@ -1016,9 +1016,9 @@ def test_a_stream_sharded_over_logical_ranks_equals_one_context(hip_lib, world, 
             assert torch.equal(got[p], want[p]), f"plane {p}: sharded stream differs from the single context"
         for r in range(world):
             f = shard.frames_for_rank(n_frames, r, world, mode)[-1]
-            ref = Oracle(oracle_cfg(clip, **kw)).process([s[f].cpu().numpy() for s in src], parity=parity[f])
+            ref = Oracle(oracle_cfg(clip, **kw)).process([to_host(s[f]) for s in src], parity=parity[f])
             for p in range(clip.planes):
-                assert same(ref[p], got[p][f].cpu().numpy())
+                assert same(ref[p], to_host(got[p][f]))
     finally:
         for flt in ranks:
             flt.close()
@@ -1058,7 +1058,7 @@ def test_misaligned_device_planes_fall_back_to_the_pool_path(hip_lib, fmt):
         for f in range(N):
             want = Oracle(oracle_cfg(clip, **kw)).process(frames[f])
             for p in range(flt.nplanes):
-                got = dst[p][f].cpu().numpy().view(clip.dtype)
+                got = to_host(dst[p][f]).view(clip.dtype)
                 assert same(want[p], got), f"{fmt} frame {f} plane {p}"
 
 
@@ -1086,7 +1086,7 @@ def test_field_orders_and_double_height_at_2160_rows_through_the_sweeps(hip_lib,
         assert flt.info().fused_frames == N
         for f in range(N):
             want = Oracle(oracle_cfg(clip, **kw)).process(frames[f], parity=parity[f])
-            assert same(want[0], dst[0][f].cpu().numpy().view(clip.dtype)), f"{fmt} {kw} frame {f}"
+            assert same(want[0], to_host(dst[0][f]).view(clip.dtype)), f"{fmt} {kw} frame {f}"
 
 
 @pytest.mark.parametrize("mode", ["fused", "pool"])
@@ -1353,7 +1353,7 @@ def test_row_bands_with_several_frames_per_launch(hip_lib, monkeypatch, fmt, w, 
         assert flt.info().banded_frames == n
         for f in range(n):
             for p in range(clip.planes):
-                got = dst[p][f].cpu().numpy().view(clip.dtype)
+                got = to_host(dst[p][f]).view(clip.dtype)
                 assert same(want[f][p], got), f"frame {f} plane {p}: " + describe_diff(want[f][p], got)
     # the host ring: groups of one or two frames per launch
     with SangNom2(clip, host_depth=4, **kw) as flt:
@@ -1430,7 +1430,7 @@ def test_launches_of_hundreds_of_small_frames_stay_on_the_whole_plane_sweeps(hip
             flt.synchronize()
             info = flt.info()
             assert (info.fused_frames, info.banded_frames) == (N, 0)
-            outs[mode] = [d.cpu().numpy() for d in dst]
+            outs[mode] = [to_host(d) for d in dst]
     for p in range(3):
         assert np.array_equal(outs["auto"][p], outs["fused"][p])
 

@@ -12,6 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avisynth_sangnom2_amd import ClipFormat, SangNom2, clip_format, synth  # noqa: E402
 from oracle.oracle import Config, Oracle  # noqa: E402
+from tests.util import to_host  # noqa: E402
 
 FORMATS = ["Y8", "Y8", "Y8", "Y10", "Y16", "Y32", "YUV420P8", "YUV420P8", "YUV420P16", "YUV422P8", "YUV444P8", "YUV444PS", "YUV420PS"]
 
@@ -107,7 +108,7 @@ def main():
                 torch.cuda.synchronize()
                 flt.process_batch(src, dst, parity=parity)
                 flt.synchronize()
-                got = [[dst[p][f].cpu().numpy().view(clip.dtype) for p in range(clip.planes)] for f in range(nframes)]
+                got = [[to_host(dst[p][f]).view(clip.dtype) for p in range(clip.planes)] for f in range(nframes)]
             else:
                 slots = flt.host_slots()
                 inflight = []
