@@ -33,7 +33,7 @@ SN_SMALL_AUTO, SN_SMALL_SWEEP = 0, 1
 # What a filter object asks for when its caller says nothing (all zeros = the library's defaults).  The test suite
 # changes entries here (small clips would otherwise never reach the whole-plane sweeps); the library itself reads no
 # environment variable.
-POLICY_DEFAULTS = {"small_launches": SN_SMALL_AUTO, "chain": 0, "copy_threads": 0, "scratch_budget_mb": 0}
+POLICY_DEFAULTS = {"small_launches": SN_SMALL_AUTO, "chain": 0, "copy_threads": 0, "scratch_budget_mb": 0, "chroma_sweeps": 0}
 
 
 class SnConfig(ctypes.Structure):
@@ -44,8 +44,8 @@ class SnConfig(ctypes.Structure):
 
 
 class SnPolicy(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("struct_size", "small_launches", "chain", "copy_threads", "scratch_budget_mb")] + [
-        ("reserved", ctypes.c_int32 * 3)]
+    _fields_ = [(n, ctypes.c_int32) for n in ("struct_size", "small_launches", "chain", "copy_threads", "scratch_budget_mb", "chroma_sweeps")] + [
+        ("reserved", ctypes.c_int32 * 2)]
 
 
 def policy(**over) -> "SnPolicy":
@@ -60,7 +60,7 @@ class SnInfo(ctypes.Structure):
                 ("pool_stride", ctypes.c_int32), ("pool_rows", ctypes.c_int32),
                 ("fused_eligible", ctypes.c_int32), ("history_free", ctypes.c_int32),
                 ("frames", ctypes.c_int64), ("fused_frames", ctypes.c_int64),
-                ("coupled_rows", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("coupled_rows", ctypes.c_int32), ("uv_sweeps", ctypes.c_int32),
                 ("threshold", ctypes.c_double * 3),
                 ("banded_frames", ctypes.c_int64), ("band_fallbacks", ctypes.c_int64),
                 ("chained_frames", ctypes.c_int64)]

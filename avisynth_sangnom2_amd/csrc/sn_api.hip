@@ -30,6 +30,7 @@ struct Context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool counted_live = false;  // this context is counted in g_live_contexts[device]
+    int64_t uv_frames = 0;      // frames whose U and V passes ran as one sweep (sn_fused_u8_uv.hip)
 
     int out_height = 0;  // vi.height after dh, SangNom2.cpp:284-285
     int stride_e = 0;    // SangNom2.cpp:287
@@ -539,6 +540,7 @@ static const char* policy_text(const sn_policy* p)
         return "sn_policy.chain must be 0 (on), -1 (off), or 1, 2, 4, 8 (workgroups per cost buffer of a chain)";
     if (p->copy_threads < 0 || p->copy_threads > 16) return "sn_policy.copy_threads must be 0..16";
     if (p->scratch_budget_mb < 0) return "sn_policy.scratch_budget_mb must not be negative";
+    if (p->chroma_sweeps != 0 && p->chroma_sweeps != 1) return "sn_policy.chroma_sweeps must be 0 (U and V as one sweep) or 1 (a sweep each)";
     return nullptr;
 }
 
@@ -1079,6 +1081,10 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         const int nr_c = c->plane_h_out(1) / 2 - 1;
         const int reach = c->fpool_rows - 1;
         const int sweep_u = nr_c + 1 < c->bh - 1 ? nr_c + 1 : c->bh - 1;
+        // 8-bit: U and V as ONE sweep (sn_fused_u8_uv.hip) -- only the luma -> U hand-off goes through a pool
+        const bool one_chroma_sweep = c->cfg.bytes_per_sample == 1 && c->policy.chroma_sweeps == 0 && pa[1].enabled && pa[2].enabled &&
+                                      pa[1].w == pa[2].w && pa[1].h_out == pa[2].h_out && pa[1].h_in == pa[2].h_in &&
+                                      sn::fused_uv_ok(c->cfg.width, pa[1].w, pa[1].h_out / 2, c->bh);
         for (int i = 0; i < n; i += c->fslots) {
             const int m = n - i < c->fslots ? n - i : c->fslots;
             for (int p = 0; p < 3; ++p) {
@@ -1103,11 +1109,16 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
                     fp.rows_out = p == 1 ? sweep_u : 0;
                 }
                 const sn::PlaneArgs a = frames_from(pa[p], i);
+                if (p == 1 && one_chroma_sweep) {
+                    SN_HIP(c, sn::launch_fused_u8_uv(st, a, frames_from(pa[2], i), c->threshold(1), c->threshold(2), m, fp));
+                    break;
+                }
                 if (c->cfg.bytes_per_sample == 4) SN_HIP(c, sn::launch_fused_f32_v3(st, a, c->threshold(p), m, &fp));
                 else if (c->cfg.bytes_per_sample == 2) SN_HIP(c, sn::launch_fused_u16_v3(st, a, c->threshold(p), m, &fp));
                 else SN_HIP(c, sn::launch_fused_u8_v3(st, a, c->threshold(p), m, &fp));
             }
         }
+        if (one_chroma_sweep) c->uv_frames += n;
         c->fused_frames += n;
         return SN_OK;
     }
@@ -1867,7 +1878,7 @@ int sn_get_info(sn_context* h, sn_info* info)
     info->frames = c->frames;
     info->fused_frames = c->fused_frames;
     info->coupled_rows = c->fused420 ? c->fpool_rows : 0;
-    info->reserved0 = 0;
+    info->uv_sweeps = c->uv_frames > 0 ? 1 : 0;
     info->banded_frames = c->banded_frames;
     info->chained_frames = c->chained_frames;
     info->band_fallbacks = 0;
@@ -1911,6 +1922,7 @@ int sn_set_policy(sn_context* h, const sn_policy* policy)
     c->policy.small_launches = policy->small_launches;
     c->policy.chain = policy->chain;
     c->policy.copy_threads = policy->copy_threads;  // (a copier that already runs keeps its threads)
+    c->policy.chroma_sweeps = policy->chroma_sweeps;
     return SN_OK;
 }
 

@@ -114,6 +114,11 @@ int64_t fused_v3_pool_bytes(int sweep_w, int rows);
 // host: scatter one scratch pool (thread-slot layout) into [9][rows][sweep_w] samples (test hook)
 void fused_v3_pool_unpack(const uint32_t* raw, int sweep_w, int rows, uint8_t* out);
 hipError_t launch_fused_u8_v3(hipStream_t s, const PlaneArgs& p, double threshold, int nframes, const FusedPool* pool);
+// sn_fused_u8_uv.hip: the U and V passes of an 8-bit 4:2:0 frame as one sweep (U in the low halves of the registers, V in the
+// high halves two rows behind); `pool`: sweep_w, pool_in / frame_stride / pool_rows / rows_in = the luma sweep's hand-off
+// pool, sweep_rows = the U pass's last row.
+bool fused_uv_ok(int sweep_w, int region_w, int nk_c, int bh);
+hipError_t launch_fused_u8_uv(hipStream_t s, const PlaneArgs& pu, const PlaneArgs& pv, double thr_u, double thr_v, int nframes, const FusedPool& pool);
 #ifdef SN_EXPERIMENT_V4  // tools/experiments/sn_fused_u8_v4.hip (four waves per SIMD; slower: profiles/r2_v4_experiment.md)
 bool fused_v4_plane_ok(int w);
 int fused_v4_waves(int w);

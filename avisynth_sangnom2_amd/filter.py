@@ -67,7 +67,7 @@ class SangNom2:
                  device: int = 0, max_batch: int = 1, mode: str = "auto", stream: int | None = None,
                  host_depth: int = 0, isolated_planes: bool = False, fresh_pool: bool = False,
                  small_launches: int | None = None, chain: int | None = None, copy_threads: int | None = None,
-                 scratch_budget_mb: int | None = None):
+                 scratch_budget_mb: int | None = None, chroma_sweeps: int | None = None):
         # `threads` is a dummy in the reference (README.md:40-41); `opt` picks its CPU code path.
         if opt < -1 or opt > 1:
             raise SangNomError(capi.SN_ERR_CONFIG, "SangNom2: opt must be between -1..2.")  # sic, SangNom2.cpp:420
@@ -85,7 +85,8 @@ class SangNom2:
         self._h = ctypes.c_void_p()
         # scheduling only (sn_policy, sangnom_hip.h); None = capi.POLICY_DEFAULTS.  chain: 0 on, -1 off, 1 / 2 / 4 / 8 = on with
         # at most that many workgroups per cost buffer
-        pol = capi.policy(small_launches=small_launches, chain=chain, copy_threads=copy_threads, scratch_budget_mb=scratch_budget_mb)
+        pol = capi.policy(small_launches=small_launches, chain=chain, copy_threads=copy_threads, scratch_budget_mb=scratch_budget_mb,
+                          chroma_sweeps=chroma_sweeps)
         rc = self._lib.sn_create_with_policy(ctypes.byref(cfg), ctypes.byref(pol), ctypes.byref(self._h))
         if rc != capi.SN_OK:
             self._h = None

@@ -110,7 +110,10 @@ typedef struct sn_policy {
                                  * at most 16.  Takes effect when the context first needs them                      */
     int32_t scratch_budget_mb;  /* device scratch per kind (pool slots; hand-off pools of the coupled sweeps; the    *
                                  * chain's ring takes an eighth); 0 = 24576.  Read at creation only                  */
-    int32_t reserved[3];        /* zero                                                                            */
+    int32_t chroma_sweeps;      /* 8-bit 4:2:0 clips in the sweeps: 0 = U and V as ONE sweep where the geometry allows *
+                                 * (sn_fused_u8_uv.hip: the U -> V hand-off stays in registers), 1 = one sweep per      *
+                                 * chroma plane with a hand-off pool between them (rounds 1-3).  May change any time   */
+    int32_t reserved[2];        /* zero                                                                            */
 } sn_policy;
 
 /* Geometry and counters of a live context. */
@@ -126,7 +129,8 @@ typedef struct sn_info {
                                * ran in row bands and whose chroma ran on the pool kernels counts) */
     int32_t coupled_rows;     /* rows per buffer the fused 4:2:0 sweeps hand from plane to   *
                                * plane (0: this configuration has no such hand-off)          */
-    int32_t reserved0;
+    int32_t uv_sweeps;        /* 1 once U and V of a 4:2:0 frame have run as ONE sweep on this *
+                               * context (8-bit; sn_policy.chroma_sweeps), else 0              */
     double  threshold[3];     /* aaf[plane] after conversion to the sample type              */
     int64_t banded_frames;    /* ... of fused_frames, swept in row bands (small launches)    */
     int64_t band_fallbacks;   /* ... of which the check sent to the pool path (up to the     *

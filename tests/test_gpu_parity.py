@@ -387,8 +387,11 @@ def test_fused_420_hand_off_rows_match_the_shared_pool(hip_lib, fmt, w, h):
         d[0::2] = src[p][0::2]     # order=1 keeps the even lines (offset 0, SangNom2.cpp:344-351)
         n._plane(d, 0, p)
         want.append(n.pool.copy())
-    with SangNom2(clip, mode="fused", **kw) as flt:
+    # (8-bit: U and V run as one sweep by default, which keeps the U -> V hand-off in registers -- sn_fused_u8_uv.hip; the
+    # two-sweep form with its second pool is sn_policy.chroma_sweeps = 1, and is what shows that hand-off here)
+    with SangNom2(clip, mode="fused", chroma_sweeps=1, **kw) as flt:
         flt.get_frame(src)
+        assert flt.info().uv_sweeps == 0
         rows = flt.info().coupled_rows
         nr_c, bh = h // 4 - 1, (h + 1) // 2
         assert rows == min(nr_c + 2, bh - 1) + 1
@@ -1452,3 +1455,54 @@ def test_coupled_sweeps_equal_the_pool_path_where_the_cone_reaches_the_last_colu
                 outs[mode] = flt.get_frame(src)
         for p in range(3):
             assert same(outs["pool"][p], outs["fused"][p]), f"{pattern} plane {p}: " + describe_diff(outs["pool"][p], outs["fused"][p])
+
+
+# The U and V passes of an 8-bit 4:2:0 frame as ONE sweep (sn_fused_u8_uv.hip).  Geometries by where the chroma region's
+# right edge falls among the strips of the luma-wide pool (62 lanes of 8 columns in the first strip, 60 in every later one):
+# inside a single strip (256, 512), exactly on a seam so that TWO waves hold both chroma and stale lanes (992), two lanes
+# into a strip (1024, 3840), in the middle of one (1280, 2560), with one to eight strips, and frames just tall enough.
+UV_GEOMETRIES = [(256, 64), (512, 640), (640, 32), (992, 720), (1024, 360), (1280, 720), (1472, 200), (1920, 1080), (2560, 96), (3200, 128),
+                 (3840, 32), (3840, 1080)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", UV_GEOMETRIES, ids=[f"{w}x{h}" for w, h in UV_GEOMETRIES])
+def test_u_and_v_as_one_sweep_match_oracle_and_the_two_sweep_form(hip_lib, w, h):
+    """Three frames per launch (every field order and parity), against one oracle instance per configuration and against the
+    two-sweep form (sn_policy.chroma_sweeps = 1); the one-sweep path is asserted to have run."""
+    import torch
+    clip = clip_format("YUV420P8", w, h)
+    dev = torch.device("cuda:0")
+    for kw, parity, pattern in ((dict(order=1, aa=48, aac=48), [1, 1, 1], "noise"), (dict(order=0, aa=128, aac=128), [1, 0, 1], "edges"),
+                                (dict(order=2, aa=0, aac=10), [1, 1, 1], "noise"), (dict(order=1, aa=48, aac=48, dh=True), [1, 1, 1], "checker")):
+        frames = [synth.frame(clip, pattern, seed=3 * w + h + i) for i in range(3)]
+        ora = Oracle(oracle_cfg(clip, **kw))
+        want = [ora.process(fr, parity=parity[i]) for i, fr in enumerate(frames)]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).pin_memory().to(dev) for p in range(3)]
+        got = {}
+        for name, extra in (("one", {}), ("two", dict(chroma_sweeps=1))):
+            with SangNom2(clip, max_batch=3, mode="fused", **kw, **extra) as flt:
+                dst = [torch.zeros((3,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(3)]
+                torch.cuda.synchronize()
+                flt.process_batch(src, dst, parity=parity)
+                flt.synchronize()
+                assert flt.info().uv_sweeps == (1 if name == "one" else 0)
+                got[name] = [to_host(d) for d in dst]
+        for f in range(3):
+            for p in range(3):
+                assert same(want[f][p], got["one"][p][f]), f"{kw} frame {f} plane {p}: " + describe_diff(want[f][p], got["one"][p][f])
+                assert np.array_equal(got["one"][p][f], got["two"][p][f])
+
+
+@pytest.mark.gpu
+def test_geometries_the_one_sweep_form_does_not_take_keep_the_two_chroma_sweeps(hip_lib):
+    """4:2:2 (the pool has no row below the chroma planes' last one) and frames of a few lines fall back; still exact."""
+    for fmt, w, h in (("YUV422P8", 512, 64), ("YUV420P8", 512, 24)):
+        clip = clip_format(fmt, w, h)
+        src = synth.frame(clip, "noise", seed=9)
+        want = Oracle(oracle_cfg(clip, aa=48, aac=48)).process(src)
+        with SangNom2(clip, mode="fused", aa=48, aac=48) as flt:
+            got = flt.get_frame(src)
+            assert flt.info().uv_sweeps == 0 and flt.info().fused_frames == 1
+        for p in range(3):
+            assert same(want[p], got[p])
