@@ -85,7 +85,7 @@ struct Mail {
 // what a step needs besides the lines (wave-uniform unless noted)
 struct Step {
     int s;                    // step: U row s, V row s - kSkew
-    int vin;                  // per lane: voffset of the luma pool's row s + 1 for this lane, or out of range
+    int vin2;                 // per lane: voffset of the luma pool's row s + 2 for this lane (fetched a step ahead), or out of range
     unsigned sel[4];          // per lane: v_perm selectors that put byte k of the luma row into bits 0..7 and -- where the lane
                               // takes last step's O for the V half -- its bits 0..7 into bits 16..23
     unsigned cmask;           // MASKED: halves whose next line pair exists (costs count)
@@ -123,7 +123,7 @@ __device__ __forceinline__ u32x2 own_bytes(const RawHalf& h, bool first)
 // One cost buffer of one step in a wave that holds chroma columns.
 // STALE: some lanes re-smooth stale values (class RS, and the masked steps of both region classes).
 // MASKED: the first kSkew and the last kSkew + 1 steps (see Step).
-template <int BUF, bool STALE, bool MASKED>
+template <int BUF, bool STALE, bool MASKED, bool PARK>
 __device__ __forceinline__ void region_buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const WideLine& n, const WideLine& nn, const Ctx& cx,
                                                    const Step& st, const u32x2& ld)
 {
@@ -146,7 +146,7 @@ __device__ __forceinline__ void region_buffer_step(unsigned (&A)[PXL], unsigned 
         // (V's last row, MASKED: a chroma lane finds last step's O in the U half of its own A -- st.amask left it there, in
         // the lanes that published to its ghosts as well; a lane that re-smooths has it in the park, refreshed through the mailbox)
         unsigned pw[PXL];
-        if (cx.opark != nullptr) {
+        if constexpr (PARK) {
             const uint4 p0 = cx.opark[(BUF * 2 + 0) * 64 + cx.lane], p1 = cx.opark[(BUF * 2 + 1) * 64 + cx.lane];
             pw[0] = p0.x; pw[1] = p0.y; pw[2] = p0.z; pw[3] = p0.w;
             pw[4] = p1.x; pw[5] = p1.y; pw[6] = p1.z; pw[7] = p1.w;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void region_buffer_step(unsigned (&A)[PXL], unsigned 
         kmin[j] = pk_min(kmin[j], key);
     }
     if constexpr (STALE) {
-        if (cx.opark != nullptr) {  // (wave-uniform; class R runs this code only in its masked steps, without a park)
+        if constexpr (PARK) {  // (class R runs this code only in its masked steps, without a park)
             cx.opark[(BUF * 2 + 0) * 64 + cx.lane] = make_uint4(O[0], O[1], O[2], O[3]);
             cx.opark[(BUF * 2 + 1) * 64 + cx.lane] = make_uint4(O[4], O[5], O[6], O[7]);
         }
@@ -192,26 +192,23 @@ __device__ __forceinline__ u32x2 issue_stale(const Ctx& cx, int b, int row, int 
 }
 
 // The nine buffers and stage 3 of one step of a region wave; returns the interpolated bytes of both passes.
-template <bool STALE, bool MASKED>
-__device__ __forceinline__ Out region_row(unsigned (&A)[kBuffers][PXL], const WideLine& n, const WideLine& nn, const Ctx& cx, const Step& st, unsigned thr_key)
+template <bool STALE, bool MASKED, bool PARK>
+__device__ __forceinline__ Out region_row(unsigned (&A)[kBuffers][PXL], const WideLine& n, const WideLine& nn, const Ctx& cx, const Step& st, unsigned thr_key,
+                                          u32x2 (&ahead)[kBuffers])
 {
     unsigned kmin[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;
-    u32x2 s0{}, s1{};  // stale rows of the even / odd buffers in flight (two buffer steps of lead)
-    if constexpr (STALE) {
-        s0 = issue_stale(cx, 0, st.s + 1, st.vin);
-        s1 = issue_stale(cx, 1, st.s + 1, st.vin);
-    }
+    // STALE: `ahead` holds the luma pass's row s + 1, fetched a whole step ago (a trip to HBM is longer than two buffer steps);
+    // each buffer's registers are refilled with row s + 2 as soon as the buffer step has read them
     auto run = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
-        u32x2& cur = (B & 1) ? s1 : s0;
-        const u32x2 ld = cur;
+        const u32x2 ld = ahead[B];
         if constexpr (STALE) {
-            __builtin_amdgcn_sched_barrier(0);  // (keeps the nine fetches from being hoisted to the top: their registers would spill)
-            if constexpr (B + 2 < kBuffers) cur = issue_stale(cx, B + 2, st.s + 1, st.vin);
+            __builtin_amdgcn_sched_barrier(0);  // (the refill must not be hoisted above the read of the same registers' previous content)
+            ahead[B] = issue_stale(cx, B, st.s + 2, st.vin2);
         }
-        region_buffer_step<B, STALE, MASKED>(A[B], kmin, n, nn, cx, st, ld);
+        region_buffer_step<B, STALE, MASKED, PARK>(A[B], kmin, n, nn, cx, st, ld);
         if constexpr (!STALE) __builtin_amdgcn_sched_barrier(0);
     };
     run(std::integral_constant<int, 0>{});
@@ -259,8 +256,11 @@ __device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], unsigned (
     }
 }
 
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
+// The sweep of one wave of class CLS.  Each class is a function of its own (sweep_entry, not inlined into the kernel): one
+// function holding all three made the register allocator spill a line of the plain steps to scratch, and a scratch reload
+// waits for every load issued before it -- the prefetched lines, the luma pass's rows -- i.e. for HBM, in every row.
+template <int NW, int CLS>
+__device__ __forceinline__ void sweep(const Args& a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int f = (int)blockIdx.x;
@@ -285,8 +285,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
     const int x0 = gl * PXL;
     const bool chroma = live && x0 < a.region_w;   // the lane's columns belong to the chroma planes
     const bool stale = live && !chroma;            // ... hold what the previous pass left
-    const int cls = __builtin_amdgcn_readfirstlane(__any((int)chroma) ? (__any((int)stale) ? (int)kRS : (int)kR) : (int)kS);
-
     cx.role.first_mask = live && gl == 0 ? kAll : 0u;
     cx.role.last_mask = live && gl == a.nl - 1 ? kAll : 0u;
     cx.role.line_last_mask = chroma && x0 + PXL == a.region_w ? kAll : 0u;
@@ -323,7 +321,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
     // LDS
     uint4* const lds4 = reinterpret_cast<uint4*>(lds_raw);
     cx.lines = lds4 + (wave < a.nreg ? wave : 0) * 15 * 64;
-    cx.opark = cls == kRS ? lds4 + a.nreg * 15 * 64 + (wave - (a.nreg - a.nrs)) * 2 * kBuffers * 64 : nullptr;
+    cx.opark = CLS == kRS ? lds4 + a.nreg * 15 * 64 + (wave - (a.nreg - a.nrs)) * 2 * kBuffers * 64 : nullptr;
     cx.mb.a = reinterpret_cast<unsigned*>(lds4 + a.nreg * 15 * 64 + a.nrs * 2 * kBuffers * 64);
     cx.mb.o = cx.mb.a + mailbox_words(NW);
     cx.mb.nw = NW;
@@ -350,14 +348,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
     auto refresh_due = [](int s) { return s > 1 && (s - 1) % K == 0; };
     auto publish_due = [&](int s) { return s % K == 0 && s < last_step; };
 
-    if (cls == kS) {
+    if constexpr (CLS == kS) {
         // ---------------- right of the region: re-smooth, hand O from the U half to the V half, leave when out of the cone
         unsigned A[kBuffers][PXL], Oprev[kBuffers][PXL];
+        u32x2 ahead[kBuffers];  // the luma pass's row for the next step, one load per buffer in flight
         {
-            const int v1 = luma_row(1);
+            const int v1 = luma_row(1), v2 = luma_row(2);
             auto init = [&](auto buf) {
                 constexpr int B = decltype(buf)::value;
                 const u32x2 q = issue_stale(cx, B, 1, v1);
+                ahead[B] = issue_stale(cx, B, 2, v2);
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) {
                     A[B][j] = __builtin_amdgcn_perm(0u, j < 4 ? q.x : q.y, 0x0c0c0c00u + (unsigned)(j & 3));  // A[1] = O[0] + D[1], O[0] = 0
@@ -392,14 +392,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
                         }
                 }
             }
-            const int vin = luma_row(s + 1);
+            const int vin2 = luma_row(s + 2);
             const unsigned omask = s <= kSkew ? 0x000000ffu : 0x00ff00ffu;  // the V half starts from zero: A'[hi] = D
-            u32x2 s0 = issue_stale(cx, 0, s + 1, vin), s1 = issue_stale(cx, 1, s + 1, vin);
             auto run = [&](auto buf) {
                 constexpr int B = decltype(buf)::value;
-                u32x2& cur = (B & 1) ? s1 : s0;
-                const u32x2 ld = cur;
-                if constexpr (B + 2 < kBuffers) cur = issue_stale(cx, B + 2, s + 1, vin);
+                const u32x2 ld = ahead[B];  // row s + 1, fetched a whole step ago
+                __builtin_amdgcn_sched_barrier(0);
+                ahead[B] = issue_stale(cx, B, s + 2, vin2);
                 stale_buffer_step<B>(A[B], Oprev[B], cx.role, ld, omask);
             };
             run(std::integral_constant<int, 0>{});
@@ -425,8 +424,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
             }
         }
         return;
-    }
-
+    } else {
     // ---------------- waves that hold chroma columns (classes R and RS)
     int src_step[2], src_line[2], dst_step[2], dst_line[2];
 #pragma unroll
@@ -451,6 +449,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
 
     WideLine L0, L1;
     unsigned A[kBuffers][PXL];
+    u32x2 ahead[kBuffers] = {};  // stale steps: the luma pass's row for the next step (see region_row)
+    auto fetch_ahead = [&](int q) {
+        const int v = luma_row(q);
+#pragma unroll
+        for (int b = 0; b < kBuffers; ++b) ahead[b] = issue_stale(cx, b, q, v);
+    };
     const unsigned thr_key = ((unsigned)((a.thr[0] + 1) << 4) & 0xffffu) | ((unsigned)((a.thr[1] + 1) << 4) << 16);
     Raw qn;
     {
@@ -468,7 +472,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
         park_raw_at(cx.lines + 1 * 5 * 64, 64, lane, R);  // K_U[1]: n of U's row 1
         // A[1] = O[0] + D[1] = D[1]: the costs of the first line pair where the lane is chroma, what the luma pass left in row 1
         // where it is not (the V half is set by the first kSkew steps)
-        const int v1 = cls == kRS ? luma_row(1) : kOutOfRange;
+        const int v1 = CLS == kRS ? luma_row(1) : kOutOfRange;
         auto init = [&](auto buf) {
             constexpr int B = decltype(buf)::value;
             const u32x2 q = issue_stale(cx, B, 1, v1);
@@ -486,6 +490,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
         init(std::integral_constant<int, 7>{});
         init(std::integral_constant<int, 8>{});
         qn = load_lines(2, 0);  // step 1 unpacks K_U[2] and K_V[0]
+        fetch_ahead(2);         // ... and reads the luma pass's row 2 where it re-smooths
     }
 
     // One step.  n = (K_U[s], K_V[s - 2]), nn receives (K_U[s + 1], K_V[s - 1]) from the prefetched qn.
@@ -520,7 +525,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
                 for (int b = 0; b < kBuffers; ++b)
 #pragma unroll
                     for (int j = 0; j < PXL; ++j) A[b][j] = bfi(cx.ghost_mask, fa[b * PXL + j], A[b][j]);
-                if (cx.opark != nullptr) {  // last step's O of the ghost lanes, for the lanes among them that re-smooth
+                if constexpr (CLS == kRS) {  // last step's O of the ghost lanes, for the lanes among them that re-smooth
                     const uint4* fo = reinterpret_cast<const uint4*>(cx.mb.o + at);
 #pragma unroll
                     for (int k = 0; k < 2 * kBuffers; ++k) cx.opark[k * 64 + lane] = fo[k];
@@ -529,11 +534,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
         }
         st.slot_c = (s - 1) % 3;
         st.slot_n = s % 3;
-        st.vin = kOutOfRange;
+        st.vin2 = kOutOfRange;
         st.cmask = st.omask = st.amask = kAll;
         st.from_a = false;
         if constexpr (STALE) {
-            st.vin = luma_row(s + 1);
+            st.vin2 = luma_row(s + 2);
             // the V half takes last step's O where the lane re-smooths; in the V pass's last row (row nr: its next costs do not
             // exist, SangNom2.cpp:74-124 writes rows 1 .. nr only) every lane does
             const bool prev = MASKED ? (stale || s - kSkew == nr) : stale;
@@ -548,7 +553,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
             st.amask = ru == nr + 1 ? kHi : kAll;  // U's last row: its half of A keeps O alone, which is what V's last row needs
             st.from_a = rv == nr;
         }
-        const Out o = region_row<STALE, MASKED>(A, n, nn, cx, st, thr_key);
+        const Out o = region_row<STALE, MASKED, CLS == kRS>(A, n, nn, cx, st, thr_key, ahead);
         {
             const int ru = s, rv = s - kSkew;
             u32x2 lo, hi;
@@ -567,7 +572,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
                 ta[b * 2 + 0] = make_uint4(A[b][0], A[b][1], A[b][2], A[b][3]);
                 ta[b * 2 + 1] = make_uint4(A[b][4], A[b][5], A[b][6], A[b][7]);
             }
-            if (cx.opark != nullptr) {
+            if constexpr (CLS == kRS) {
                 uint4* to = reinterpret_cast<uint4*>(cx.mb.o + at);
 #pragma unroll
                 for (int k = 0; k < 2 * kBuffers; ++k) to[k] = cx.opark[k * 64 + lane];
@@ -583,7 +588,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
     const int plain_from = kSkew + 1, plain_to = nr;  // [plain_from, plain_to)
     for (int s = 1; s <= last_step; ++s) {
         if (s == plain_from && plain_from < plain_to) {
-            if (cls == kR) {
+            if constexpr (CLS == kR) {
                 for (; s + 1 < plain_to; s += 2) {
                     step(s, L1, L0, F{}, F{});
                     step(s + 1, L0, L1, F{}, F{});
@@ -593,6 +598,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
                     L1 = L0;
                     ++s;
                 }
+                fetch_ahead(plain_to + 1);  // (the plain steps fetch nothing; the masked steps that follow read a row ahead)
             } else {
                 for (; s < plain_to; ++s) {
                     step(s, L1, L0, T{}, F{});
@@ -610,6 +616,37 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
         keep(0, (2 * nk - 1) * a.dst_pitch[0], q, vstore);
         keep(1, (2 * nk - 1) * a.dst_pitch[1], q, vstore);
     }
+    }  // region classes
+}
+
+// (an argument of a device function travels in vector registers and the compiler must take it for divergent: every word of
+// the argument block goes through v_readfirstlane once, so that in the sweep rows, pitches and pointers are scalars again --
+// as they are in a kernel that reads its own argument segment)
+template <int NW, int CLS>
+__device__ __attribute__((noinline)) void sweep_entry(const Args* from)
+{
+    static_assert(sizeof(Args) % 4 == 0, "Args is copied word by word");
+    constexpr int kWords = (int)(sizeof(Args) / 4);
+    const uint32_t* in = reinterpret_cast<const uint32_t*>(from);
+    uint32_t words[kWords];
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) words[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)in[i]);
+    Args a;
+    __builtin_memcpy(&a, words, sizeof a);
+    sweep<NW, CLS>(a);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
+{
+    // the class of this wave, from its lanes' columns (ghost lanes included); the rest of the geometry is derived in sweep()
+    const int tid = (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int gl = wave == 0 ? lane : kFirst + kInner * (wave - 1) + (lane - GH);
+    const bool live = gl < a.nl, chroma = live && gl * PXL < a.region_w, stale = live && !chroma;
+    const int cls = __builtin_amdgcn_readfirstlane(__any((int)chroma) ? (__any((int)stale) ? (int)kRS : (int)kR) : (int)kS);
+    if (cls == kS) sweep_entry<NW, kS>(&a);
+    else if (cls == kR) sweep_entry<NW, kR>(&a);
+    else sweep_entry<NW, kRS>(&a);
 }
 
 }  // namespace uv
