@@ -63,7 +63,7 @@ class SnInfo(ctypes.Structure):
                 ("coupled_rows", ctypes.c_int32), ("uv_sweeps", ctypes.c_int32),
                 ("threshold", ctypes.c_double * 3),
                 ("banded_frames", ctypes.c_int64), ("band_fallbacks", ctypes.c_int64),
-                ("chained_frames", ctypes.c_int64)]
+                ("chained_frames", ctypes.c_int64), ("chain_redone", ctypes.c_int64)]
 
 
 def build(force: bool = False) -> str:

@@ -122,7 +122,9 @@ struct Context {
     uint8_t* chain_base = nullptr;
     int chain_slots = 0, chain_origin = 0;
     uint32_t* chain_flags = nullptr;   // 8-bit chains over several workgroups per buffer: their round counters (device) ...
-    uint32_t* chain_status = nullptr;  // ... and the word a workgroup raises when it gave up waiting (host memory the device writes)
+    uint32_t* chain_status = nullptr;  // host memory the device writes: launches of chains over several workgroups that timed out and were
+                                       // redone on one workgroup per buffer (running count, mirrored after every such launch)
+    bool chain_force_fault = false;    // sn_debug_raise_chain_fault: the next such launch starts with its fault word up
     int64_t chained_frames = 0;
     uint32_t* band_state = nullptr;
     int32_t* band_flags = nullptr;
@@ -1182,6 +1184,9 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
 // flight, stage 3 of all passes.  The pool of slot 0 is where the chain starts and where its last pass's pool ends
 // up, so frames that come one at a time (and the pool's readers) carry on from there.
 constexpr size_t kChainFlagBytes = (size_t)sn::kBuffers * sn::kChainMaxGroups * 32 * sizeof(uint32_t);
+// behind the round counters: [0] the fault word of the launch in flight (zeroed with the counters), [32] launches redone so far
+constexpr size_t kChainFaultWord = kChainFlagBytes / sizeof(uint32_t), kChainRedoneWord = kChainFaultWord + 32;
+constexpr size_t kChainFlagAlloc = kChainFlagBytes + 64 * sizeof(uint32_t);
 #ifndef SN_CHAIN_DEFAULT_GROUPS
 #define SN_CHAIN_DEFAULT_GROUPS 8
 #endif
@@ -1230,7 +1235,7 @@ static int ensure_chain(Context* c, int pn, hipStream_t st)
         return SN_CHAIN_UNAVAILABLE;
     }
     // the round counters and the status word of chains over several workgroups: without them the ring is no use (all or nothing)
-    if (hipMalloc(reinterpret_cast<void**>(&c->chain_flags), kChainFlagBytes) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&c->chain_flags), kChainFlagAlloc) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->chain_status), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         if (c->chain_flags) (void)hipFree(c->chain_flags);
@@ -1242,21 +1247,19 @@ static int ensure_chain(Context* c, int pn, hipStream_t st)
         return SN_CHAIN_UNAVAILABLE;
     }
     *c->chain_status = 0;
+    SN_HIP(c, hipMemsetAsync(c->chain_flags, 0, kChainFlagAlloc, st));
     SN_HIP(c, hipMemsetAsync(c->chain_base, 0, (size_t)c->pool.slot_bytes * c->chain_slots, st));
     c->chain_origin = 0;
     return SN_OK;
 }
 
-// A workgroup of a chain over several workgroups gave up waiting for the one before it (sn_pool_kernels.hip,
-// k_smooth_u8_chain<true>): the frames of that launch are wrong.  Sticky: checked wherever the library has just waited for
-// the device, and before it queues anything else.
-static int chain_fault(Context* c)
-{
-    if (c->chain_status && __atomic_load_n(c->chain_status, __ATOMIC_RELAXED) != 0)
-        return sn::fail(c, SN_ERR_HIP, "a chain of passes timed out between two workgroups (sn_policy.chain = 1 keeps a buffer's chain on one workgroup); "
-                                       "the frames of that launch are invalid and the context must be recreated");
-    return SN_OK;
-}
+// A workgroup of a chain over several workgroups that gives up waiting for the one before it (sn_pool_kernels.hip, ChainSync:
+// it was never scheduled next to its neighbour -- e.g. another context's sweep holds every CU slot, the reference's
+// MT_MULTI_INSTANCE model, src/SangNom2.h:63-66) raises the launch's fault word.  Round 3 turned that into a sticky error
+// after wrong frames had been delivered.  Now every such launch is followed by its own guarded redo (run_chain): stage 1 of
+// all passes again and the chain on ONE workgroup per buffer, which waits for nobody; they exit at once unless the word is
+// up.  The count of redone launches travels to sn_info.chain_redone.
+static int chain_fault(Context*) { return SN_OK; }
 
 // Workgroups per buffer for a chain of npass passes.  A short chain -- a single frame's two or three passes, two frames --
 // stays on one workgroup, where a pass follows its predecessor without a trip through memory: 720x480 YUV420P8, one frame
@@ -1317,11 +1320,16 @@ static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3]
         ch.pn = pn;
         ch.origin = c->chain_origin;
         ch.groups = chain_groups(c, ch.npass);
+        uint32_t* const fault = c->chain_flags ? c->chain_flags + kChainFaultWord : nullptr;
         if (ch.groups > 1) {
             ch.slack = kChainSlack;
             ch.flags = c->chain_flags;
-            ch.status = c->chain_status;
-            SN_HIP(c, hipMemsetAsync(c->chain_flags, 0, kChainFlagBytes, st));
+            ch.status = fault;
+            SN_HIP(c, hipMemsetAsync(c->chain_flags, 0, kChainFlagBytes + sizeof(uint32_t), st));  // round counters and the fault word
+            if (c->chain_force_fault) {  // test hook: as if the launch timed out at once
+                SN_HIP(c, hipMemsetAsync(fault, 1, 1, st));
+                c->chain_force_fault = false;
+            }
         }
         for (int k = 0; k < pn; ++k) {
             sn::PlaneArgs a = pa[planes[k]];
@@ -1332,6 +1340,30 @@ static int run_chain(Context* c, hipStream_t st, int n, const void* const src[3]
             SN_HIP(c, sn::launch_pool_prepare(st, a, ring, B, m, (c->chain_origin + 1 + k) % c->chain_slots));
         }
         SN_HIP(c, sn::launch_pool_chain(st, ring, ch, B));
+        if (ch.groups > 1) {
+            // the guarded redo (see chain_fault): the costs again -- stage 2 has smoothed them in place -- and the chain on one
+            // workgroup per buffer; every cell a pass's slot holds is rewritten by one of the two, the slot the chain starts
+            // from (the copy of the pool before this launch) is only ever read
+            sn::PoolArgs guarded = ring;
+            guarded.guard = reinterpret_cast<const int32_t*>(fault);
+            guarded.guard_single = 1;
+            for (int k = 0; k < pn; ++k) {
+                sn::PlaneArgs a = pa[planes[k]];
+                a.src += (int64_t)i * a.src_frame_stride;
+                a.dst += (int64_t)i * a.dst_frame_stride;
+                a.guard = reinterpret_cast<const int32_t*>(fault);
+                a.guard_single = 1;
+                SN_HIP(c, sn::launch_pool_prepare(st, a, guarded, B, m, (c->chain_origin + 1 + k) % c->chain_slots));
+            }
+            sn::ChainArgs again = ch;
+            again.groups = 1;
+            again.slack = 0;
+            again.flags = nullptr;
+            again.status = nullptr;
+            again.only_if = fault;
+            SN_HIP(c, sn::launch_pool_chain(st, ring, again, B));
+            SN_HIP(c, sn::launch_chain_redo_count(st, fault, c->chain_flags + kChainRedoneWord, c->chain_status));
+        }
         for (int k = 0; k < pn; ++k) {
             sn::PlaneArgs a = pa[planes[k]];
             a.src += (int64_t)i * a.src_frame_stride;
@@ -1879,6 +1911,7 @@ int sn_get_info(sn_context* h, sn_info* info)
     info->fused_frames = c->fused_frames;
     info->coupled_rows = c->fused420 ? c->fpool_rows : 0;
     info->uv_sweeps = c->uv_frames > 0 ? 1 : 0;
+    info->chain_redone = c->chain_status ? (int64_t)__atomic_load_n(c->chain_status, __ATOMIC_RELAXED) : 0;
     info->banded_frames = c->banded_frames;
     info->chained_frames = c->chained_frames;
     info->band_fallbacks = 0;
@@ -1931,7 +1964,7 @@ int sn_debug_raise_chain_fault(sn_context* h)
     Context* c = reinterpret_cast<Context*>(h);
     if (!c) return sn::fail(nullptr, SN_ERR_INVALID_ARG, "ctx is NULL");
     if (!c->chain_status) return sn::fail(c, SN_ERR_UNSUPPORTED, "sn_debug_raise_chain_fault: this context has not run a chain");
-    __atomic_store_n(c->chain_status, 1u, __ATOMIC_RELAXED);
+    c->chain_force_fault = true;
     return SN_OK;
 }
 

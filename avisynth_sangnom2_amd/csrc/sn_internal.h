@@ -26,6 +26,7 @@ struct PlaneArgs {
     int32_t dh;
     int32_t enabled;           // processPlane[i] || dh
     const int32_t* guard;      // pool-path kernels: when set, frame f is worked on only if guard[f] != 0 (sn_band.hip)
+    int32_t guard_single;      // ... 1: ONE word decides for every frame of the launch (guard[0]; the redo of a chain that timed out)
 };
 
 // Scratch pool geometry (src/SangNom2.cpp:287-288,305-310), in elements of T.
@@ -35,6 +36,7 @@ struct PoolArgs {
     int32_t stride_e;          // roundup(luma width, 32)
     int32_t bh;                // bufferHeight; a buffer has bh + 1 rows
     const int32_t* guard;      // as PlaneArgs::guard
+    int32_t guard_single;      // as PlaneArgs::guard_single
     int32_t rows;              // stage 2 stops before this pool row (0 = bh: the whole pool, as the reference does)
     int32_t slot_step = 0;     // k_prepare / k_finalize: frame f uses slot (slot0 + f * slot_step) % slot_mod
     int32_t slot_mod = 0;      // (0 / 0: slot0 + f)
@@ -50,7 +52,9 @@ struct ChainArgs {
     int32_t origin;
     int32_t groups, slack;  // 8-bit: workgroups per buffer (<= 1: one) and the rounds of slack between two of them
     uint32_t* flags;        // groups > 1: kBuffers * kChainMaxGroups * 32 words, zero at launch (rounds completed per workgroup)
-    uint32_t* status;       // groups > 1: host-visible word, set when a workgroup stopped waiting for the one before it
+    uint32_t* status;       // groups > 1: device word, set when a workgroup stopped waiting for the one before it (zero at launch
+                            // unless a test forces the fault: then every wait is skipped, as after a real time-out)
+    const uint32_t* only_if;  // != nullptr: the launch runs only if this word is not zero (the guarded redo on one workgroup per buffer)
     int32_t rows;           // > 0: stage 2 stops there (rows 1 .. rows - 1 are smoothed), as PoolArgs::rows
     int32_t nchains, chain_step;  // nchains > 1: that many independent chains of npass passes (blockIdx.y), chain y starting at
                                   // slot origin + y * chain_step (> npass; no wrap around the ring; one workgroup per buffer)
@@ -72,6 +76,8 @@ hipError_t launch_pool_prepare(hipStream_t s, const PlaneArgs& p, const PoolArgs
 hipError_t launch_pool_finalize(hipStream_t s, const PlaneArgs& p, const PoolArgs& pool, int bytes, double threshold, int nframes,
                                 int slot0);
 hipError_t launch_pool_chain(hipStream_t s, const PoolArgs& pool, const ChainArgs& chain, int bytes);
+// after the guarded redo of a chain launch: *redone += (*fault != 0), and the running count into *host_mirror (host memory the device writes)
+hipError_t launch_chain_redo_count(hipStream_t s, const uint32_t* fault, uint32_t* redone, uint32_t* host_mirror);
 
 // sn_fused_select.hip: which configurations the fused sweeps serve.  A fused launch also does the plane's frame
 // assembly, so launch_assemble must not be called for a plane it serves.

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_assemble(PlaneArgs p, int row_bytes)
 {
     const int y = blockIdx.y;
     const int f = blockIdx.z;
-    if (p.guard && p.guard[f] == 0) return;
+    if (p.guard && p.guard[p.guard_single ? 0 : f] == 0) return;
     const int sy = assemble_source_row(p, y);
     if (sy < 0) return;
     const uint8_t* s = p.src + (int64_t)f * p.src_frame_stride + (int64_t)sy * p.src_pitch;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) k_prepare(PlaneArgs p, PoolArgs pool, int
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int f = blockIdx.z;
-    if (p.guard && p.guard[f] == 0) return;
+    if (p.guard && p.guard[p.guard_single ? 0 : f] == 0) return;
     if (x >= p.w) return;
     const uint8_t* plane = p.dst + (int64_t)f * p.dst_frame_stride;
     const T* cl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y) * p.dst_pitch);
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(PoolArgs pool, int sl
     W* line1 = line0 + se;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     T* buf = reinterpret_cast<T*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     // the workgroup has ceil(se / NC) threads rounded up to whole waves; the idle lanes of the last wave compute on
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8x2(PoolArgs pool, i
     uint4* line1 = line0 + nt;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     uint8_t* buf = pool.base + slot_of(pool, slot0, f) * pool.slot_bytes + (size_t)b * bufsz;
     const int tid = threadIdx.x;
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u8_strips(PoolArgs po
     const int nw = (int)blockDim.x >> 6;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     uint8_t* buf = pool.base + slot_of(pool, slot0, f) * pool.slot_bytes + (size_t)b * bufsz;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -441,7 +441,9 @@ __device__ __forceinline__ void chain_release_barrier()
 // publishes "rounds < round are complete" (chain_release_barrier() drained every wave's stores), and the waves of its first slot make sure
 // the workgroup before it has completed round `round - 1 - slack` -- with the value they fetched while the round before
 // ran if that is enough (in step it is: the schedule starts a workgroup's slots `slack` rounds late), polling otherwise,
-// for two seconds at most: then the workgroup gives up waiting for good and raises the host-visible status word.
+// for two seconds at most: then the workgroup gives up waiting for good and raises the launch's fault word, which the guarded
+// launches that follow every chain over several workgroups read: stage 1 again and the chain on ONE workgroup per buffer
+// (nothing to wait for there), so the frames are right whatever happened (sn_api.hip, run_chain).
 struct ChainSync {
     unsigned* mine;
     const unsigned* his;
@@ -456,7 +458,9 @@ struct ChainSync {
         status = ch.status;
         slack = ch.slack;
         seen = 0;
-        gave_up = false;
+        // (a fault word that is already up -- sn_debug_raise_chain_fault -- makes every wave skip its waits from the start: the
+        // launch then produces what a launch that timed out produces, rows taken before they were written)
+        gave_up = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     }
     __device__ __forceinline__ void enter(int round, bool first_slot, int tid)
     {
@@ -469,7 +473,7 @@ struct ChainSync {
                 while ((int)(seen = __hip_atomic_load(his, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
                     if (++spins > kChainSpinLimit) {
                         gave_up = true;
-                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(8);
@@ -523,8 +527,9 @@ constexpr int kChain8Threads = SN_CHAIN8_THREADS;
 //     starts workgroup g's slots g * slack rounds late, so in step that counter is `slack` rounds old news: the waves look
 //     at the value they fetched while the round before ran (a fresh poll is a trip to memory on the round's critical path,
 //     which cost 7 - 10 % of the rate with four and eight workgroups) and poll only if that is not enough;
-//   * a wait is bounded: after two seconds and more a workgroup gives up waiting for good and raises ChainArgs::status,
-//     which the host turns into an error (a workgroup that was never scheduled must not hang the GPU);
+//   * a wait is bounded: after two seconds and more a workgroup gives up waiting for good and raises ChainArgs::status
+//     (a workgroup that was never scheduled -- another context's sweep holding every CU slot -- must not hang the GPU);
+//     the launch is then redone on one workgroup per buffer by the guarded launches queued behind it (ChainArgs::only_if);
 //   * a pass's first rows come from memory as well: they are fetched at the start of the pass's first round and taken
 //     into the registers at its end (LATE_PRIME), not waited for on the spot.
 // 720x480 YUV420P8, 512 frames per launch: 23.1 k frames/s with one workgroup per buffer, 28.4 k with two, 31.5 k with
@@ -551,6 +556,7 @@ __global__ void __launch_bounds__(THREADS) k_smooth_u8_chain(PoolArgs pool, Chai
 {
     using namespace v3c;
     extern __shared__ __align__(16) unsigned char smem[];
+    if (ch.only_if && *ch.only_if == 0) return;  // the guarded redo of a launch that did not time out: nothing to do
     constexpr unsigned kLo = 0x0000ffffu, kHi = 0xffff0000u;
     const int se = pool.stride_e;
     const int nl = se >> 3;  // lanes that own columns
@@ -859,6 +865,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_chain(PoolArgs po
 {
     using namespace v3c;
     extern __shared__ __align__(16) unsigned char smem[];
+    if (ch.only_if && *ch.only_if == 0) return;  // the guarded redo of a launch that did not time out: nothing to do
     const int se = pool.stride_e;
     const int nl = se >> 3;  // lanes that own columns
     const int groups = GROUPED ? ch.groups : 1, slack = GROUPED ? ch.slack : 0;
@@ -1007,6 +1014,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_chain(PoolArgs po
 {
     using namespace v3c;
     extern __shared__ __align__(16) unsigned char smem[];
+    if (ch.only_if && *ch.only_if == 0) return;  // the guarded redo of a launch that did not time out: nothing to do
     const int se = pool.stride_e;
     const int nl = se >> 3;  // lanes that own columns
     const int groups = GROUPED ? ch.groups : 1, slack = GROUPED ? ch.slack : 0;
@@ -1167,7 +1175,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16x8(PoolArgs pool, 
     uint4* line1 = line0 + 2 * nt;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x;
@@ -1253,7 +1261,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_u16_strips(PoolArgs p
     const int nw = (int)blockDim.x >> 6;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     uint16_t* buf = reinterpret_cast<uint16_t*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1365,7 +1373,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32x8(PoolArgs pool, 
     float4* line1 = line0 + 2 * nt;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     float* buf = reinterpret_cast<float*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x;
@@ -1455,7 +1463,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_f32_strips(PoolArgs p
     const int nw = (int)blockDim.x >> 6;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     float* buf = reinterpret_cast<float*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1569,7 +1577,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth_strided(PoolArgs pool
     W* line1 = line0 + se;
     const int b = blockIdx.x;
     const int f = blockIdx.y;
-    if (pool.guard && pool.guard[f] == 0) return;
+    if (pool.guard && pool.guard[pool.guard_single ? 0 : f] == 0) return;
     const size_t bufsz = (size_t)se * (pool.bh + 1);
     T* buf = reinterpret_cast<T*>(pool.base + slot_of(pool, slot0, f) * pool.slot_bytes) + (size_t)b * bufsz;
     const int tid = threadIdx.x;
@@ -1635,7 +1643,7 @@ k_finalize(PlaneArgs p, PoolArgs pool, int slot0, typename Px<T>::W thr)
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int f = blockIdx.z;
-    if (p.guard && p.guard[f] == 0) return;
+    if (p.guard && p.guard[p.guard_single ? 0 : f] == 0) return;
     if (x >= p.w) return;
     uint8_t* plane = p.dst + (int64_t)f * p.dst_frame_stride;
     const T* cl = reinterpret_cast<const T*>(plane + (int64_t)(p.offset + 2 * y) * p.dst_pitch);
@@ -1808,6 +1816,18 @@ int pool_chain_groups(int bytes, int stride_e, int want)
     int g = 1;
     while (g * 2 <= want && g * 2 <= kChainMaxGroups && chain_waves(bytes, g * 2) >= nw) g *= 2;
     return g;
+}
+
+__global__ void k_chain_redo_count(const uint32_t* fault, uint32_t* redone, uint32_t* host_mirror)
+{
+    if (*fault != 0) *redone += 1;  // (launches of one context are ordered: one thread, no atomics)
+    *host_mirror = *redone;
+}
+
+hipError_t launch_chain_redo_count(hipStream_t st, const uint32_t* fault, uint32_t* redone, uint32_t* host_mirror)
+{
+    hipLaunchKernelGGL(k_chain_redo_count, dim3(1), dim3(1), 0, st, fault, redone, host_mirror);
+    return hipGetLastError();
 }
 
 hipError_t launch_pool_chain(hipStream_t st, const PoolArgs& pool, const ChainArgs& chain, int bytes)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 3
+#define SN_ABI_VERSION 4
 
 typedef struct sn_context sn_context;
 
@@ -138,6 +138,12 @@ typedef struct sn_info {
     int64_t chained_frames;   /* frames of a history-carrying clip whose passes ran as one   *
                                * chain (several frames per launch, or one frame with two or  *
                                * three processed planes) instead of one pass at a time       */
+    int64_t chain_redone;     /* launches of such chains over several workgroups per buffer  *
+                               * in which a workgroup gave up waiting for its neighbour (it   *
+                               * was not scheduled next to it in time) and which were redone  *
+                               * on one workgroup per buffer before their frames were handed  *
+                               * on (up to the last synchronisation); the frames are right    *
+                               * either way                                                   */
 } sn_info;
 
 /* Create_SangNom2's argument checks, same order, same message text (src/SangNom2.cpp:407-422).
@@ -270,10 +276,10 @@ int sn_debug_read_coupled_rows(sn_context* ctx, int32_t which, void* host_dst, s
  * turns the bands off; warm_rows = 0 restores the default run-up.  A run-up of 1 makes nearly every frame fail. */
 int sn_debug_set_bands(sn_context* ctx, int32_t bands, int32_t warm_rows);
 
-/* Test hook for the chains over several workgroups per cost buffer (sn_policy.chain): raises the word a workgroup
- * raises when it gives up waiting for the workgroup before it, as if the last chain had timed out.  Every later call
- * that queues work or waits for the device then fails with SN_ERR_HIP; the context has to be recreated.
- * SN_ERR_UNSUPPORTED if the context has not run a chain yet (the word lives with the chain's ring). */
+/* Test hook for the chains over several workgroups per cost buffer (sn_policy.chain): the NEXT such launch starts with
+ * its fault word up, as if a workgroup had given up waiting at once -- its waves then take rows before they are written,
+ * as after a real time-out -- so that the guarded redo behind the launch has something to repair.  The frames must come
+ * out right and sn_info.chain_redone must count the launch.  SN_ERR_UNSUPPORTED if the context has not run a chain yet. */
 int sn_debug_raise_chain_fault(sn_context* ctx);
 
 int sn_abi_version(void);

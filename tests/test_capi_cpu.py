@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(hip_lib, name), f"libsangnom_hip.so does not export {name}"
-    assert hip_lib.sn_abi_version() == 3  # 2: + sn_aa_* (round 2); 3: + sn_policy (round 3)
+    assert hip_lib.sn_abi_version() == 4  # 2: + sn_aa_* (round 2); 3: + sn_policy (round 3); 4: sn_info.chain_redone, sn_policy.chroma_sweeps (round 4)
 
 
 def test_the_library_reads_no_environment_variable(hip_lib):

@@ -579,30 +579,41 @@ def test_host_ring_groups_of_a_history_carrying_clip_run_as_chains(hip_lib):
             assert same(want[p], got[f][p]), f"frame {f} plane {p}: " + describe_diff(want[p], got[f][p])
 
 
-def test_a_chain_that_timed_out_fails_every_later_call(hip_lib):
-    """A workgroup that gives up waiting for the one before it raises a host-visible word (k_smooth_*_chain<true>); from
-    then on the context refuses to queue work and reports the fault wherever it waits for the device."""
+def test_a_chain_launch_that_timed_out_is_redone_on_one_workgroup_per_buffer(hip_lib):
+    """A workgroup of a chain over several workgroups per buffer that gives up waiting for the one before it raises the
+    launch's fault word; the guarded launches queued behind every such launch -- stage 1 again, the chain on one workgroup per
+    buffer -- then redo it before stage 3 runs.  The hook starts the next launch with the word up, so that its waves skip
+    every wait (they take rows before they are written: the launch really goes wrong); the frames still equal the oracle's,
+    the pool carried into the next launch as well, and sn_info.chain_redone counts the launch."""
     import torch
     from avisynth_sangnom2_amd.filter import SangNomError
-    clip = clip_format("Y8", 1000, 56)
-    frames = make_frames(clip, "noise", 12, seed0=5)
-    dev = torch.device("cuda:0")
-    with SangNom2(clip, max_batch=12) as flt:
-        src = [torch.from_numpy(np.stack([fr[0] for fr in frames])).pin_memory().to(dev)]
-        dst = [torch.zeros((12,) + flt.plane_shape_out(0), dtype=torch.uint8, device=dev)]
-        torch.cuda.synchronize()
-        flt.process_batch(src, dst)
-        flt.synchronize()
-        assert flt.info().chained_frames == 12
-        flt.raise_chain_fault()
-        with pytest.raises(SangNomError, match="timed out between two workgroups") as e:
-            flt.synchronize()
-        assert e.value.code == capi_code("SN_ERR_HIP")
-        with pytest.raises(SangNomError, match="timed out between two workgroups"):
-            flt.process_batch(src, dst)
-        with pytest.raises(SangNomError, match="timed out between two workgroups"):
-            flt.get_frame(frames[0])
-    with SangNom2(clip) as flt:  # no chain yet: nothing to raise
+    for fmt in ("Y8", "Y16", "Y32", "YUV420P8"):
+        clip = clip_format(fmt, 1008 if fmt == "YUV420P8" else 1000, 56)  # (a chain needs planes a multiple of 8 wide: 504-wide chroma)
+        N = 24
+        frames = make_frames(clip, "noise", 3 * N, seed0=5)
+        ora = Oracle(oracle_cfg(clip, aac=48))
+        want = [ora.process(fr) for fr in frames]
+        dev = torch.device("cuda:0")
+        tdt = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[clip.bytes]
+        vdt = {1: np.uint8, 2: np.int16, 4: np.float32}[clip.bytes]
+        with SangNom2(clip, max_batch=N, aac=48, chain=8) as flt:
+            for launch in range(3):
+                part = frames[launch * N:(launch + 1) * N]
+                src = [torch.from_numpy(np.stack([fr[p] for fr in part]).view(vdt)).pin_memory().to(dev) for p in range(clip.planes)]
+                dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=tdt, device=dev) for p in range(clip.planes)]
+                torch.cuda.synchronize()
+                if launch == 1:
+                    flt.raise_chain_fault()
+                flt.process_batch(src, dst)
+                flt.synchronize()
+                info = flt.info()
+                assert info.chained_frames == (launch + 1) * N
+                assert info.chain_redone == (1 if launch >= 1 else 0), (fmt, launch, info.chain_redone)
+                for f in range(N):
+                    for p in range(clip.planes):
+                        got = to_host(dst[p][f]).view(clip.dtype)
+                        assert same(want[launch * N + f][p], got), f"{fmt} launch {launch} frame {f} plane {p}: " + describe_diff(want[launch * N + f][p], got)
+    with SangNom2(clip_format("Y8", 1000, 56)) as flt:  # no chain yet: nothing to raise
         with pytest.raises(SangNomError, match="has not run a chain"):
             flt.raise_chain_fault()
 
@@ -1506,3 +1517,80 @@ def test_geometries_the_one_sweep_form_does_not_take_keep_the_two_chroma_sweeps(
             assert flt.info().uv_sweeps == 0 and flt.info().fused_frames == 1
         for p in range(3):
             assert same(want[p], got[p])
+
+
+@pytest.mark.gpu
+def test_chaining_contexts_next_to_a_context_that_fills_the_device(hip_lib):
+    """The reference's concurrency model (MT_MULTI_INSTANCE, SangNom2.h:63-66) on the chains: four threads, each with a
+    context of its own, run a history-carrying 720x480 YUV420P8 clip as chains of 64 frames over EIGHT workgroups per cost
+    buffer (72 workgroups that wait for each other around a ring), while a fifth context keeps launching 512-frame 2160p
+    sweeps on its own stream -- more workgroups than the device holds at a time.  A chain workgroup that is not scheduled
+    next to its neighbour in time gives up and the launch is redone on one workgroup per buffer (chain_redone); either way
+    every frame equals its oracle instance and no call fails."""
+    import threading
+    import torch
+    clip = clip_format("YUV420P8", 720, 480)
+    kw = dict(aa=48, aac=48)
+    T, N, LAUNCHES = 4, 64, 3
+    dev = torch.device("cuda:0")
+    frames = [[synth.frame(clip, "noise" if (t + f) % 5 else "edges", seed=1000 * t + f) for f in range(N * LAUNCHES)] for t in range(T)]
+    want = []
+    for t in range(T):
+        ora = Oracle(oracle_cfg(clip, **kw))
+        want.append([ora.process(fr) for fr in frames[t]])
+    got = [[None] * (N * LAUNCHES) for _ in range(T)]
+    redone = [0] * T
+    errors = []
+    stop = threading.Event()
+
+    def chains(t):
+        try:
+            with SangNom2(clip, max_batch=N, chain=8, **kw) as flt:
+                for launch in range(LAUNCHES):
+                    part = frames[t][launch * N:(launch + 1) * N]
+                    src = [torch.from_numpy(np.stack([fr[p] for fr in part])).pin_memory().to(dev) for p in range(3)]
+                    dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(3)]
+                    torch.cuda.synchronize()
+                    flt.process_batch(src, dst)
+                    flt.synchronize()
+                    host = [to_host(d) for d in dst]
+                    for f in range(N):
+                        got[t][launch * N + f] = [host[p][f] for p in range(3)]
+                info = flt.info()
+                assert info.chained_frames == N * LAUNCHES
+                redone[t] = int(info.chain_redone)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    def sweeps():
+        try:
+            big = clip_format("Y8", 3840, 2160)
+            M = 512
+            with SangNom2(big, max_batch=M, aa=48) as flt:
+                g = torch.Generator(device=dev)
+                g.manual_seed(5)
+                src = [torch.randint(0, 256, (M, 2160, 3840), device=dev, generator=g, dtype=torch.uint8)]
+                dst = [torch.empty_like(src[0])]
+                torch.cuda.synchronize()
+                while not stop.is_set():
+                    for _ in range(4):
+                        flt.process_batch(src, dst)
+                    flt.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(("sweeps", repr(e)))
+
+    bg = threading.Thread(target=sweeps)
+    bg.start()
+    ths = [threading.Thread(target=chains, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    stop.set()
+    bg.join()
+    assert not errors, errors
+    for t in range(T):
+        for f in range(N * LAUNCHES):
+            for p in range(3):
+                assert same(want[t][f][p], got[t][f][p]), f"thread {t} frame {f} plane {p} (launches redone: {redone})"
+    print("chain launches redone per context:", redone)
