@@ -31,6 +31,7 @@ struct Context {
     bool own_stream = false;
     bool counted_live = false;  // this context is counted in g_live_contexts[device]
     int64_t uv_frames = 0;      // frames whose U and V passes ran as one sweep (sn_fused_u8_uv.hip)
+    bool uv_geometry = false;   // ... and whether this clip's geometry allows that (then only the luma -> U pool exists from the start)
 
     int out_height = 0;  // vi.height after dh, SangNom2.cpp:284-285
     int stride_e = 0;    // SangNom2.cpp:287
@@ -403,6 +404,17 @@ static int ensure_pool(Context* c, int plane = 0)
     return SN_OK;
 }
 
+// A hand-off pool of the coupled sweeps (0: luma -> U, 1: U -> V), fslots frames of it.
+static int ensure_fpool(Context* c, int i)
+{
+    if (c->fpool[i]) return SN_OK;
+    SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->fslots));
+    // cells outside the hand-off's dependency cone are never written: zero, so that the debug read-back is defined
+    SN_HIP(c, hipMemsetAsync(c->fpool[i], 0, (size_t)c->fpool_frame_bytes * c->fslots, c->stream));
+    if (i == 1) SN_HIP(c, hipStreamSynchronize(c->stream));  // allocated late: its first user may be a ring slot's stream
+    return SN_OK;
+}
+
 static int create_impl(const sn_config* cfg, Context* c)
 {
     c->cfg = *cfg;
@@ -510,23 +522,28 @@ static int create_impl(const sn_config* cfg, Context* c)
                        : cfg->bytes_per_sample == 2 ? sn::fused_u16_waves(cfg->width)
                                                     : sn::fused_v3_waves(cfg->width);
         const int round = 256 * (8 / nw);
-        c->fslots = fit(2 * c->fpool_frame_bytes);  // fused420 implies history-free (fused_eligible)
+        // 8-bit clips whose U and V passes run as one sweep (sn_fused_u8_uv.hip) need the luma -> U pool only; the U -> V pool of
+        // the two-sweep form is allocated when that form first runs (sn_policy.chroma_sweeps = 1, or a launch of planes the one
+        // sweep does not take)
+        c->uv_geometry = cfg->bytes_per_sample == 1 && c->plane_w(1) == c->plane_w(2) && c->plane_h_out(1) == c->plane_h_out(2) &&
+                         sn::fused_uv_ok(cfg->width, c->plane_w(1), c->plane_h_out(1) / 2, c->bh);
+        const int npools = c->uv_geometry ? 1 : 2;
+        c->fslots = fit(npools * c->fpool_frame_bytes);  // fused420 implies history-free (fused_eligible)
         if (c->fslots < round && scratch_budget_is_default(c)) {
             // wide float frames: a chunk below one round leaves compute units idle in every launch, so the hand-off
             // pools may take up to a quarter of the device's memory to reach one
             size_t free_b = 0, total_b = 0;
             SN_HIP(c, hipMemGetInfo(&free_b, &total_b));
-            const int64_t cap = (int64_t)(total_b / 4 < free_b / 2 ? total_b / 4 : free_b / 2) / (2 * c->fpool_frame_bytes);
+            const int64_t cap = (int64_t)(total_b / 4 < free_b / 2 ? total_b / 4 : free_b / 2) / (npools * c->fpool_frame_bytes);
             const int64_t want = c->cfg.max_batch > c->host_depth ? c->cfg.max_batch : c->host_depth;
             int64_t n = cap < round ? cap : round;
             if (n > want) n = want;
             if (n > c->fslots) c->fslots = (int)n;
         }
         if (c->fslots > round) c->fslots -= c->fslots % round;
-        for (int i = 0; i < 2; ++i) {
-            SN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->fpool[i]), (size_t)c->fpool_frame_bytes * c->fslots));
-            // cells outside the hand-off's dependency cone are never written: zero, so that the debug read-back is defined
-            SN_HIP(c, hipMemsetAsync(c->fpool[i], 0, (size_t)c->fpool_frame_bytes * c->fslots, c->stream));
+        for (int i = 0; i < npools; ++i) {
+            const int rc2 = ensure_fpool(c, i);
+            if (rc2 != SN_OK) return rc2;
         }
     }
     SN_HIP(c, hipStreamSynchronize(c->stream));
@@ -1084,9 +1101,11 @@ static int run_group(Context* c, hipStream_t st, int slot0, int n, const void* c
         const int reach = c->fpool_rows - 1;
         const int sweep_u = nr_c + 1 < c->bh - 1 ? nr_c + 1 : c->bh - 1;
         // 8-bit: U and V as ONE sweep (sn_fused_u8_uv.hip) -- only the luma -> U hand-off goes through a pool
-        const bool one_chroma_sweep = c->cfg.bytes_per_sample == 1 && c->policy.chroma_sweeps == 0 && pa[1].enabled && pa[2].enabled &&
-                                      pa[1].w == pa[2].w && pa[1].h_out == pa[2].h_out && pa[1].h_in == pa[2].h_in &&
-                                      sn::fused_uv_ok(c->cfg.width, pa[1].w, pa[1].h_out / 2, c->bh);
+        const bool one_chroma_sweep = c->uv_geometry && c->policy.chroma_sweeps == 0 && pa[1].enabled && pa[2].enabled && pa[1].h_in == pa[2].h_in;
+        if (!one_chroma_sweep) {
+            const int rc2 = ensure_fpool(c, 1);
+            if (rc2 != SN_OK) return rc2;
+        }
         for (int i = 0; i < n; i += c->fslots) {
             const int m = n - i < c->fslots ? n - i : c->fslots;
             for (int p = 0; p < 3; ++p) {

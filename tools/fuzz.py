@@ -33,7 +33,8 @@ def main():
     rng = random.Random(a.seed)
     t_end = time.time() + a.seconds
     n = bad = 0
-    stats = {"fused": 0, "pool": 0, "ring": 0, "host": 0, "batch": 0, "frames": 0, "pixels": 0, "banded_frames": 0, "band_fallbacks": 0, "chained_frames": 0}
+    stats = {"fused": 0, "pool": 0, "ring": 0, "host": 0, "batch": 0, "frames": 0, "pixels": 0, "banded_frames": 0, "band_fallbacks": 0, "chained_frames": 0,
+             "uv_sweep_configs": 0, "chain_redone": 0}
     while time.time() < t_end:
         fmt = rng.choice(FORMATS)
         wide = rng.random() < 0.15
@@ -82,7 +83,9 @@ def main():
                 want.append(outs)
         small = rng.choice([1, 0])  # SN_SMALL_SWEEP: the whole-plane sweeps, or auto mode's small-launch paths (bands, pool kernels)
         try:
-            flt = SangNom2(clip, host_depth=rng.choice([1, 2, 3, 4, 5, 8, 12]), max_batch=nframes, isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", small_launches=small, **kw)
+            sweeps = rng.choice([0, 0, 0, 1])  # 8-bit 4:2:0: U and V as one sweep (default) or a sweep each
+            flt = SangNom2(clip, host_depth=rng.choice([1, 2, 3, 4, 5, 8, 12]), max_batch=nframes, isolated_planes=ext == "isolated", fresh_pool=ext == "fresh", small_launches=small,
+                           chroma_sweeps=sweeps, **kw)
         except Exception as e:  # a geometry the library rejects must be one it documents
             if "exceeds the supported maximum" in str(e):
                 continue
@@ -123,6 +126,8 @@ def main():
             stats["banded_frames"] += info.banded_frames
             stats["band_fallbacks"] += info.band_fallbacks
             stats["chained_frames"] += info.chained_frames
+            stats["uv_sweep_configs"] += info.uv_sweeps
+            stats["chain_redone"] += info.chain_redone
         stats["fused" if fused else "pool"] += 1
         for f in range(nframes):
             for p in range(clip.planes):
@@ -132,7 +137,7 @@ def main():
                     np.savez(f"gpurun_out/fuzz_mismatch_{n}.npz", **{f"src{q}": frames[f][q] for q in range(clip.planes)},
                              **{f"want{q}": want[f][q] for q in range(clip.planes)}, **{f"got{q}": got[f][q] for q in range(clip.planes)})
                     print(f"MISMATCH {fmt} {w}x{h} {kw} ext={ext} way={way} frame {f}/{nframes} plane {p} pattern={pattern} parity={parity} "
-                          f"small_launches={small} bands={band_set} banded={info.banded_frames} fallbacks={info.band_fallbacks} "
+                          f"small_launches={small} chroma_sweeps={sweeps} uv={info.uv_sweeps} bands={band_set} banded={info.banded_frames} fallbacks={info.band_fallbacks} "
                           f"fused={info.fused_frames} n={len(d)} rows {d[:, 0].min()}..{d[:, 0].max()} cols {d[:, 1].min()}..{d[:, 1].max()}", flush=True)
         n += 1
         if n % 50 == 0:

@@ -27,6 +27,11 @@ CASES = [
     ("YUV420PS", 3840, 2160, dict(aa=48, aac=48), 6),
     ("YUV420P8", 512, 1024, dict(aa=128, aac=128), 64),    # 64 lanes: lanes 62 / 63 of the only strip own columns
     ("YUV422P8", 992, 540, dict(aa=128, aac=128), 48),     # 124 lanes: the same in the second strip
+    # U and V as one sweep (sn_fused_u8_uv.hip; the 2160p and 512-wide cases above take it as well): four strips with the
+    # region's edge inside the second, three strips with it inside the second, and the region's edge exactly on a seam
+    ("YUV420P8", 1920, 1080, dict(aa=48, aac=48), 32),
+    ("YUV420P8", 1280, 720, dict(aa=48, aac=128, order=2), 48),
+    ("YUV420P8", 992, 720, dict(aa=128, aac=128), 48),
 ]
 
 
