@@ -123,7 +123,7 @@ __device__ __forceinline__ u32x2 own_bytes(const RawHalf& h, bool first)
 // One cost buffer of one step in a wave that holds chroma columns.
 // STALE: some lanes re-smooth stale values (class RS, and the masked steps of both region classes).
 // MASKED: the first kSkew and the last kSkew + 1 steps (see Step).
-template <int BUF, bool STALE, bool MASKED, bool PARK>
+template <int BUF, bool STALE, bool MASKED, bool PARK, bool RC>
 __device__ __forceinline__ void region_buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const WideLine& n, const WideLine& nn, const Ctx& cx,
                                                    const Step& st, const u32x2& ld)
 {
@@ -164,7 +164,7 @@ __device__ __forceinline__ void region_buffer_step(unsigned (&A)[PXL], unsigned 
     }
 #pragma unroll
     for (int j = 0; j < PXL; ++j) S[j] = add3(A[j], U[j], V[j]);
-    box7<true>(S, Bx, cx.role);
+    box7<RC>(S, Bx, cx.role);  // RC: this wave holds the pool's last column (the select of the right-hand clamp)
     unsigned O[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
@@ -192,7 +192,7 @@ __device__ __forceinline__ u32x2 issue_stale(const Ctx& cx, int b, int row, int 
 }
 
 // The nine buffers and stage 3 of one step of a region wave; returns the interpolated bytes of both passes.
-template <bool STALE, bool MASKED, bool PARK>
+template <bool STALE, bool MASKED, bool PARK, bool RC>
 __device__ __forceinline__ Out region_row(unsigned (&A)[kBuffers][PXL], const WideLine& n, const WideLine& nn, const Ctx& cx, const Step& st, unsigned thr_key,
                                           u32x2 (&ahead)[kBuffers])
 {
@@ -208,7 +208,7 @@ __device__ __forceinline__ Out region_row(unsigned (&A)[kBuffers][PXL], const Wi
             __builtin_amdgcn_sched_barrier(0);  // (the refill must not be hoisted above the read of the same registers' previous content)
             ahead[B] = issue_stale(cx, B, st.s + 2, st.vin2);
         }
-        region_buffer_step<B, STALE, MASKED, PARK>(A[B], kmin, n, nn, cx, st, ld);
+        region_buffer_step<B, STALE, MASKED, PARK, RC>(A[B], kmin, n, nn, cx, st, ld);
         if constexpr (!STALE) __builtin_amdgcn_sched_barrier(0);
     };
     run(std::integral_constant<int, 0>{});
@@ -238,7 +238,7 @@ __device__ __forceinline__ Out region_row(unsigned (&A)[kBuffers][PXL], const Wi
 }
 
 // One cost buffer of one step in a wave right of the region (class S): D = the luma pass's row | last step's O << 16.
-template <int BUF>
+template <int BUF, bool RC>
 __device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], unsigned (&Oprev)[PXL], const LaneRole& role, const u32x2& ld, unsigned omask)
 {
     unsigned D[PXL], S[PXL], Bx[PXL];
@@ -247,7 +247,7 @@ __device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], unsigned (
         D[j] = __builtin_amdgcn_perm(Oprev[j], j < 4 ? ld.x : ld.y, 0x0c040c00u + (unsigned)(j & 3));
         S[j] = A[j] + D[j];
     }
-    box7<true>(S, Bx, role);
+    box7<RC>(S, Bx, role);
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
         const unsigned O = pk_lshr4(Bx[j]) & omask;  // (sum / 16) wraps to uint8_t, SangNom2.cpp:152
@@ -259,7 +259,7 @@ __device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], unsigned (
 // The sweep of one wave of class CLS.  Each class is a function of its own (sweep_entry, not inlined into the kernel): one
 // function holding all three made the register allocator spill a line of the plain steps to scratch, and a scratch reload
 // waits for every load issued before it -- the prefetched lines, the luma pass's rows -- i.e. for HBM, in every row.
-template <int NW, int CLS>
+template <int NW, int CLS, bool RC>
 __device__ __forceinline__ void sweep(const Args& a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -399,7 +399,7 @@ __device__ __forceinline__ void sweep(const Args& a)
                 const u32x2 ld = ahead[B];  // row s + 1, fetched a whole step ago
                 __builtin_amdgcn_sched_barrier(0);
                 ahead[B] = issue_stale(cx, B, s + 2, vin2);
-                stale_buffer_step<B>(A[B], Oprev[B], cx.role, ld, omask);
+                stale_buffer_step<B, RC>(A[B], Oprev[B], cx.role, ld, omask);
             };
             run(std::integral_constant<int, 0>{});
             run(std::integral_constant<int, 1>{});
@@ -553,7 +553,7 @@ __device__ __forceinline__ void sweep(const Args& a)
             st.amask = ru == nr + 1 ? kHi : kAll;  // U's last row: its half of A keeps O alone, which is what V's last row needs
             st.from_a = rv == nr;
         }
-        const Out o = region_row<STALE, MASKED, CLS == kRS>(A, n, nn, cx, st, thr_key, ahead);
+        const Out o = region_row<STALE, MASKED, CLS == kRS, RC>(A, n, nn, cx, st, thr_key, ahead);
         {
             const int ru = s, rv = s - kSkew;
             u32x2 lo, hi;
@@ -622,7 +622,7 @@ __device__ __forceinline__ void sweep(const Args& a)
 // (an argument of a device function travels in vector registers and the compiler must take it for divergent: every word of
 // the argument block goes through v_readfirstlane once, so that in the sweep rows, pitches and pointers are scalars again --
 // as they are in a kernel that reads its own argument segment)
-template <int NW, int CLS>
+template <int NW, int CLS, bool RC>
 __device__ __attribute__((noinline)) void sweep_entry(const Args* from)
 {
     static_assert(sizeof(Args) % 4 == 0, "Args is copied word by word");
@@ -633,7 +633,7 @@ __device__ __attribute__((noinline)) void sweep_entry(const Args* from)
     for (int i = 0; i < kWords; ++i) words[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)in[i]);
     Args a;
     __builtin_memcpy(&a, words, sizeof a);
-    sweep<NW, CLS>(a);
+    sweep<NW, CLS, RC>(a);
 }
 
 template <int NW>
@@ -644,9 +644,18 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
     const int gl = wave == 0 ? lane : kFirst + kInner * (wave - 1) + (lane - GH);
     const bool live = gl < a.nl, chroma = live && gl * PXL < a.region_w, stale = live && !chroma;
     const int cls = __builtin_amdgcn_readfirstlane(__any((int)chroma) ? (__any((int)stale) ? (int)kRS : (int)kR) : (int)kS);
-    if (cls == kS) sweep_entry<NW, kS>(&a);
-    else if (cls == kR) sweep_entry<NW, kR>(&a);
-    else sweep_entry<NW, kRS>(&a);
+    // ... and whether it holds the pool's last column: only there the box needs its right-hand clamp (a wave-uniform choice of
+    // the whole function, never a branch inside a buffer step)
+    const bool rc = __builtin_amdgcn_readfirstlane(__any((int)(live && gl == a.nl - 1)) ? 1 : 0) != 0;
+    if (cls == kS) {
+        if (rc) sweep_entry<NW, kS, true>(&a);
+        else sweep_entry<NW, kS, false>(&a);
+    } else if (cls == kR) {
+        sweep_entry<NW, kR, false>(&a);  // (the last column is never chroma: region_w < w)
+    } else {
+        if (rc) sweep_entry<NW, kRS, true>(&a);
+        else sweep_entry<NW, kRS, false>(&a);
+    }
 }
 
 }  // namespace uv
