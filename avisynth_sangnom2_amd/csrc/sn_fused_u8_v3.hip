@@ -315,9 +315,13 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
     Out o{};
     if constexpr (!S3) return o;
     // rank codes of the eight winners of each strip, four to a dword in pixel order (RawLine has the rest)
-    RawLine c, nr;
+    RawLine c{}, nr{};
+#ifndef SN_X_NO_S3_LDS
     unpark_raw(pk, tid, rc.slot_c, c);
     unpark_raw(pk, tid, rc.slot_n, nr);
+#else
+    c.W[0][0] = kmin[0]; nr.W[1][1] = kmin[1];  // (knock-out: wrong results, no LDS reads in stage 3)
+#endif
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const unsigned t01 = __builtin_amdgcn_perm(kmin[4 * g + 1], kmin[4 * g + 0], 0x06020400u);  // [lo0 lo1 hi0 hi1]
@@ -522,6 +526,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     LineOf<MODE> L0, L1;
     Raw q0 = load_raw(src_line + (r0 - 1) * src_step);
     Raw q1 = nk > 1 ? load_raw(src_line + r0 * src_step) : q0;
+    // The third line is fetched HERE, before the first stores, so that on entering the row loop the loads in flight have
+    // stores behind them, as they do when the loop comes round (a row's order is: kept-line stores, next line's loads, ...,
+    // output stores).  vmcnt counts in order: with the loads as the newest operations on ONE way into the loop header the
+    // compiler waits there with vmcnt(1) / vmcnt(0) in every other row -- i.e. for the output stores of the row just
+    // finished, a trip to memory of which a wave of an 8-wave workgroup hides nothing (4320p: wait_any 0.29) -- instead of
+    // vmcnt(3) / vmcnt(2), which only asks for loads issued a whole row ago.
+    Raw qn = r0 + 1 <= nr ? load_raw(src_line + (r0 + 1) * src_step) : q1;
     keep(dst_line, q0, top);
     if (a.offset == 1) keep(0, q0, top);  // the line that cannot be interpolated, SangNom2.cpp:386-391
     if (nk > 1) keep(dst_line + r0 * dst_step, q1, r0 == ra && r0 <= nr);
@@ -580,7 +591,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     int src_next = src_line + (r0 + 1) * src_step;
     int dst_keep = dst_line + (r0 + 1) * dst_step;
     int out_row = dst_line + a.dst_pitch + (r0 - 1) * dst_step;
-    Raw qn = r0 + 1 <= nr ? load_raw(src_next) : q1;
     src_next += src_step;
 
     // Seam exchange roles.  Lanes 60, 61 are the right seam lanes and lanes 2, 3 the left seam

@@ -218,13 +218,22 @@ struct TurnTaking {
 // workgroup are independent: each has its own slice of the dynamic LDS and they only meet at the barriers.
 __host__ __device__ constexpr int group_of(int nw) { return nw == 1 ? 4 : nw == 2 ? 2 : 1; }
 
-// slice = about a quarter of the time a sweep of nk kept lines takes (a row costs roughly 4.5 us).  Only for
-// workgroups of four waves: those put one wave on each SIMD, two workgroups fill a CU, and the partners on all four
-// SIMDs are the same two workgroups in opposite slots.  With other shapes the waves of a workgroup -- tied to each
-// other by the seam refresh -- would hold different priorities at the same time (2-wave workgroups lost 8 % with
-// turns), and an 8-wave workgroup has both waves of every SIMD itself (they cannot drift apart; turns cost 1 %).
+// slice = about a quarter of the time a sweep of nk kept lines takes (a row costs roughly 4.5 us) for workgroups of four
+// waves: those put one wave on each SIMD, two workgroups fill a CU, and the partners on all four SIMDs are the same two
+// workgroups in opposite slots.  (2-wave workgroups lost 8 % with turns: the waves of a workgroup -- tied to each other by
+// the seam refresh -- would hold different priorities at the same time.)
+// Workgroups of EIGHT waves (4320p 8-bit planes, 16-bit and float planes from 2160p on) hold both waves of every SIMD
+// themselves, waves k and k + 4.  Round 3 left them without turns ("they cannot drift apart"); they do, inside every block
+// of five rows: tools/row_timing.py (s_memtime around the phases of a row) finds a 4320p wave waiting at the seam barrier
+// for 22 % of its cycles (2160p, two workgroups per CU: 4 %) -- equal priorities are served oldest first, so wave k issues
+// whenever it can, reaches the barrier early and waits, and wave k + 4 then finishes the block alone at a single wave's
+// issue rate.  Removing the barrier gains nothing (the kernel is as slow as its slowest wave); taking turns in SHORT slices
+// does: 2^10 ticks = 10 us (two to three rows) measured best -- 4320p Y8 +3.3 %, 2160p Y16 +3.6 %, Y32 +1 %; 5 us +2 %,
+// 20 us +1 %, 40 us and more -1 % (profiles/r4_ab_experiments.md 3.).  A progress-based variant (each wave leaves its row
+// number in LDS, the one behind takes the priority) reached the same +3 % at 4320p and cost the one-sweep chroma passes 1 %.
 inline int turn_shift_for(int nk, int waves)
 {
+    if (waves == 8) return 10;
     if (waves != 4) return 0;
     int s = 10;
     while ((128ll * nk) >> (s + 1)) ++s;
