@@ -46,6 +46,17 @@ namespace sn {
 namespace v3 {
 
 using namespace v3c;
+#ifdef SN_ROW_TIMING  // tools/row_timing.py: where a wave of the plain sweep spends its shader-clock cycles, by phase of a row
+__device__ unsigned long long sn_row_cycles[8];
+#define SN_RT(k)                                                       \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        rt_acc[k] += now_ - rt_last;                                   \
+        rt_last = now_;                                                \
+    } while (0)
+#else
+#define SN_RT(k) do { } while (0)
+#endif
 [[maybe_unused]] constexpr int kMaxWaves = 8;         // physical waves per workgroup (16 virtual wavefronts, 7680 pixels)
 
 // Access to the scratch pools of the chroma coupling (see Mode).  A thread has two 8-byte chunks in a pool row:
@@ -607,14 +618,22 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
     // interpolated line).
     TurnTaking turns;
     turns.init(a.turn_shift);
+#ifdef SN_ROW_TIMING
+    unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt_last = __builtin_amdgcn_s_memtime();
+#endif
     auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag, auto store_tag) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
         constexpr bool STORE = decltype(store_tag)::value;
         turns.update();
+        SN_RT(6);
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
             const Raw fq = clamp_edges(qn, role);  // waits for the line prefetched one row ago
+#ifdef SN_ROW_TIMING
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            SN_RT(0);  // [0] the wait for the prefetched line
+#endif
             unpack(nn, fq);
             RawLine R;
             make_raw(R, fq, nn);
@@ -627,10 +646,12 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             src_next += src_step;
         }
         const int par = (r / K) & 1;
+        SN_RT(1);  // [1] unpack, windows, park, kept-line store, prefetch issue
         if (r > r0 && (r - 1) % K == 0) {
 #ifndef SN_X_NO_SEAM_BARRIER
             __syncthreads();
 #endif
+            SN_RT(2);  // [2] the seam barrier
             if (recv_left || recv_right) {
                 const unsigned* from = reinterpret_cast<const unsigned*>(mb.at(par, wave, recv_left ? 0 : 1, slot));
                 auto merge = [&](int b, unsigned (&Ab)[PXL]) {
@@ -665,8 +686,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             rc.vout_hi = (row_out && in_cone(r, a.cone_out, 1)) ? io.v_out_hi : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any((rc.vout != kOutOfRange) | (rc.vout_hi != kOutOfRange)) ? 1 : 0) != 0;
         }
+        SN_RT(3);  // [3] ghost refresh (every fifth row) and row set-up
         const Out o = row_step<MODE, HAS_NEXT, S3, STORE>(A, parked, tid, n, nn, role, thr_key, io, rc);
         if constexpr (S3) put(out_row, o);  // stored at once: nothing is carried into the next row
+        SN_RT(4);  // [4] nine buffer steps + stage 3 + output store
         out_row += dst_step;
         if (r < sweep) {
             if (r % K == 0) {
@@ -714,6 +737,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
             }
         }
         qn = qnext;
+        SN_RT(5);  // [5] publish (every fifth row)
+#ifdef SN_ROW_TIMING
+        rt_acc[7] += 1;
+#endif
     };
     using T = std::integral_constant<bool, true>;
     using F = std::integral_constant<bool, false>;
@@ -785,6 +812,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         }
     }
 
+#ifdef SN_ROW_TIMING
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&sn_row_cycles[k], rt_acc[k]);
+#endif
     // dst row h-1 := K[nk-1] when the top field is kept, SangNom2.cpp:380-385
     if (a.offset == 0 && bottom) {
         const Raw q = load_raw(src_line + (nk - 1) * src_step);
@@ -821,6 +852,18 @@ static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
     return hipGetLastError();
 }
 
+#if defined(SN_TU_PLAIN) && defined(SN_ROW_TIMING)
+extern "C" __attribute__((visibility("default"))) int sn_debug_row_cycles(unsigned long long out[8], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(v3::sn_row_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(v3::sn_row_cycles), zero, sizeof zero) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 #ifdef SN_TU_PLAIN
 hipError_t launch_fused_u8_v3_plain(hipStream_t st, const v3c::Args& a, int nframes, int mode)
 {
