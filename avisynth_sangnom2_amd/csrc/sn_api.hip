@@ -662,31 +662,43 @@ static int check_planes(Context* c, const void* const src[3], const int32_t sp[3
     return SN_OK;
 }
 
-// A fused sweep walks a plane row by row: its time hardly depends on how many frames the launch carries (up to a
-// round of resident workgroups) but it never takes less than rows x 3.5-5.7 us -- 3.8 ms for one 2160p 8-bit
-// plane.  The pool path spreads ONE frame over the whole chip (1.0 ms for that plane) and costs about 15-33 ps per
-// pool element and frame beyond that.  Both are exact, so in SN_MODE_AUTO small launches -- a synchronous GetFrame,
-// a short look-ahead -- take the pool path (measured crossover at 2160p: about 48 frames for 8-bit Y, 42 for 16-bit
-// and float, 70 for 8-bit 4:2:0; the estimate below switches a little earlier).
+// A fused sweep walks a plane row by row: its time hardly depends on how many frames the launch carries (up to a round of
+// resident workgroups) but it never takes less than rows x 2.6 - 4.7 us.  The pool path spreads ONE frame over the whole chip
+// and costs 13 - 33 ps per pool element and frame beyond that.  Both are exact, so in SN_MODE_AUTO a launch that is neither cut
+// into row bands (band_count) nor large goes to whichever this estimate says is faster.  Constants: fitted in round 4 to
+// tools/prefer_pool_calib.py (profiles/r4_prefer_pool.md: launches of 1 .. 128 device-resident frames through both paths, 1080p /
+// 2160p / 4320p, the three sample types, 4:2:0) -- round 1's had the pool path's fixed cost three times too high (stage 2 has
+// since moved to the strip kernels) and a row of a sweep that has its CU to itself 30 % too slow, which cancelled except at
+// 4320p, where launches of 16 .. 32 frames took the sweeps at up to twice the pool path's time.
+//   sweep: rows x t_row; t_row = 2.6 us (8-bit; 3.8 us for planes of more than eight strips: eight waves), 2.8 us (16-bit),
+//          4.3 us (float); the chroma planes of a coupled 4:2:0 clip sweep the luma-wide pool: 8-bit U and V as one sweep
+//          3.8 us per chroma row for both, otherwise 3.15 us (16-bit) / 4.7 us (float) per row and plane
+//   pool : bh x (a + 0.036 us x ceil(stride / 1024)) + 60 us + n x stride x bh x per_elem per processed plane;
+//          a = 0.25 / 0.22 / 0.33 us, per_elem = 12.9 / 19.4 / 32.6 ps for 8-bit / 16-bit / float
 static bool prefer_pool(const Context* c, int n, int slot0)
 {
     if (c->cfg.mode != SN_MODE_AUTO || !c->history_free || slot0 + n > c->slots) return false;
     if (sweeps_always(c)) return false;  // SN_SMALL_SWEEP (the tests use it to reach the sweeps with small clips)
     const int B = c->cfg.bytes_per_sample;
-    const double t_row = B == 1 ? 3.5e-6 : B == 2 ? 4.05e-6 : 5.7e-6;     // fused sweep, per row
-    const double per_elem = B == 1 ? 14.7e-12 : B == 2 ? 20e-12 : 32.5e-12;  // pool path, per pool element and frame
+    const double per_elem = B == 1 ? 12.9e-12 : B == 2 ? 19.4e-12 : 32.6e-12;
+    const double a_fix = B == 1 ? 0.25e-6 : B == 2 ? 0.22e-6 : 0.33e-6;
     double fused = 0, pool = 0;
     for (int p = 0; p < c->nplanes(); ++p) {
         if (!(c->cfg.dh || c->process[p])) continue;
         const bool own = c->isolated;  // own pool geometry per plane, else the luma-sized shared pool
         const int stride = own ? c->plane_pool[p].stride_e : c->stride_e;
         const int bh = own ? c->plane_pool[p].bh : c->bh;
-        const int rows = (c->fused420 ? c->out_height : c->plane_h_out(p)) / 2;
+        const int rows = c->plane_h_out(p) / 2;
+        const bool coupled_chroma = c->fused420 && p > 0;
+        double t_row = B == 1 ? (stride > 3840 ? 3.8e-6 : 2.6e-6) : B == 2 ? 2.8e-6 : 4.3e-6;
+        if (coupled_chroma) t_row = B == 1 ? (c->uv_geometry && c->policy.chroma_sweeps == 0 ? 1.9e-6 : 3.0e-6) : B == 2 ? 3.15e-6 : 4.7e-6;
         fused += rows * t_row;
         const int cols_per_thread = (stride + 1023) / 1024;
-        pool += bh * (0.35e-6 + 0.15e-6 * cols_per_thread) + 60e-6 + (double)n * stride * bh * per_elem;
+        // (a pass of the shared pool stops at the last row a later pass of this frame can still read: run_group's stop[])
+        const int bh_run = !own && rows + 2 < bh ? rows + 2 : bh;
+        pool += bh_run * (a_fix + 0.036e-6 * cols_per_thread) + 60e-6 + (double)n * stride * bh_run * per_elem;
     }
-    return pool < 0.8 * fused;
+    return pool < fused;
 }
 
 // Row bands: a launch of a few frames -- a synchronous GetFrame, a short look-ahead -- cannot fill the
