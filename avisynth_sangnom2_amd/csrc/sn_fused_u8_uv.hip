@@ -239,12 +239,13 @@ __device__ __forceinline__ Out region_row(unsigned (&A)[kBuffers][PXL], const Wi
 
 // One cost buffer of one step in a wave right of the region (class S): D = the luma pass's row | last step's O << 16.
 template <int BUF, bool RC>
-__device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], unsigned (&Oprev)[PXL], const LaneRole& role, const u32x2& ld, unsigned omask)
+__device__ __forceinline__ void stale_buffer_step(unsigned (&A)[PXL], unsigned (&Oprev)[PXL], const LaneRole& role, const u32x2& ld, unsigned omask,
+                                                  unsigned sel)
 {
     unsigned D[PXL], S[PXL], Bx[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) {
-        D[j] = __builtin_amdgcn_perm(Oprev[j], j < 4 ? ld.x : ld.y, 0x0c040c00u + (unsigned)(j & 3));
+        D[j] = __builtin_amdgcn_perm(Oprev[j], j < 4 ? ld.x : ld.y, sel + (unsigned)(j & 3));  // sel: 0x0c040c00, or 0x0c0c0c00 (no U row behind)
         S[j] = A[j] + D[j];
     }
     box7<RC>(S, Bx, role);
@@ -394,12 +395,15 @@ __device__ __forceinline__ void sweep(const Args& a)
             }
             const int vin2 = luma_row(s + 2);
             const unsigned omask = s <= kSkew ? 0x000000ffu : 0x00ff00ffu;  // the V half starts from zero: A'[hi] = D
+            // V's row s - 2 takes U's row s - 1 -- unless that row does not exist (4:2:2: the pool ends with the chroma planes' last
+            // row, so V's last row adds nothing, as its pass of the reference finds nothing below it: SangNom2.cpp:126-159)
+            const unsigned sel = s - 1 <= a.sweep_u ? 0x0c040c00u : 0x0c0c0c00u;
             auto run = [&](auto buf) {
                 constexpr int B = decltype(buf)::value;
                 const u32x2 ld = ahead[B];  // row s + 1, fetched a whole step ago
                 __builtin_amdgcn_sched_barrier(0);
                 ahead[B] = issue_stale(cx, B, s + 2, vin2);
-                stale_buffer_step<B, RC>(A[B], Oprev[B], cx.role, ld, omask);
+                stale_buffer_step<B, RC>(A[B], Oprev[B], cx.role, ld, omask, sel);
             };
             run(std::integral_constant<int, 0>{});
             run(std::integral_constant<int, 1>{});
@@ -541,7 +545,8 @@ __device__ __forceinline__ void sweep(const Args& a)
             st.vin2 = luma_row(s + 2);
             // the V half takes last step's O where the lane re-smooths; in the V pass's last row (row nr: its next costs do not
             // exist, SangNom2.cpp:74-124 writes rows 1 .. nr only) every lane does
-            const bool prev = MASKED ? (stale || s - kSkew == nr) : stale;
+            // (... if U has that row: in a 4:2:2 clip the pool ends with the chroma planes' last row and V's last row adds nothing)
+            const bool prev = MASKED ? (s - kSkew == nr ? a.sweep_u > nr : stale) : stale;
             const unsigned base = prev ? 0x0c040c00u : 0x0c0c0c00u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) st.sel[k] = base + (unsigned)k;
@@ -660,15 +665,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused_u8_uv(Args a)
 
 }  // namespace uv
 
-// Which 4:2:0 geometries the one-sweep chroma passes take; everything else keeps the two chroma sweeps of
-// sn_fused_u8_v3.hip.  Both chroma planes processed and alike, the region a whole number of lanes, the pool row nr_c + 1
-// exists (so that the U pass has its extra row and the V pass's last row finds it), enough rows for the skew.
+// Which subsampled geometries the one-sweep chroma passes take; everything else keeps the two chroma sweeps of
+// sn_fused_u8_v3.hip.  Both chroma planes processed and alike, the region a whole number of lanes, enough rows for the skew.
+// 4:2:0: the U pass has an extra row (nr_c + 1) and the V pass's last row finds it; 4:2:2: the pool ends with the chroma
+// planes' last row, the U pass has no extra row and V's last row takes nothing from it.
 bool fused_uv_ok(int sweep_w, int region_w, int nk_c, int bh)
 {
     if (sweep_w % 32 != 0 || region_w % 8 != 0 || region_w <= 0 || region_w >= sweep_w) return false;
     if (v3c::strips_for(sweep_w / v3c::PXL) > uv::kMaxWaves) return false;
     const int nr = nk_c - 1;
-    return nr >= 2 * uv::kSkew + 2 && nr + 1 <= bh - 1;
+    return nr >= 2 * uv::kSkew + 2 && nr <= bh - 1;
 }
 
 hipError_t launch_fused_u8_uv(hipStream_t st, const PlaneArgs& pu, const PlaneArgs& pv, double thr_u, double thr_v, int nframes, const FusedPool& pool)
@@ -721,7 +727,7 @@ hipError_t launch_fused_u8_uv(hipStream_t st, const PlaneArgs& pu, const PlaneAr
     a.pool_threads = fused_v3_waves(pool.sweep_w) * 64;
     a.sweep_u = pool.sweep_rows;
     a.nframes = nframes;
-    if (a.sweep_u != a.nk) return hipErrorInvalidValue;  // nr_c + 1
+    if (a.sweep_u != a.nk && a.sweep_u != a.nk - 1) return hipErrorInvalidValue;  // nr_c + 1, or nr_c where the pool has no row below (4:2:2)
     const int lds = uv::lds_bytes(nw, nreg, nrs);
     hipError_t e = hipSuccess;
 #define SN_LAUNCH(NW)                                                                                                  \

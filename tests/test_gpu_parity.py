@@ -1507,8 +1507,8 @@ def test_u_and_v_as_one_sweep_match_oracle_and_the_two_sweep_form(hip_lib, w, h)
 
 @pytest.mark.gpu
 def test_geometries_the_one_sweep_form_does_not_take_keep_the_two_chroma_sweeps(hip_lib):
-    """4:2:2 (the pool has no row below the chroma planes' last one) and frames of a few lines fall back; still exact."""
-    for fmt, w, h in (("YUV422P8", 512, 64), ("YUV420P8", 512, 24)):
+    """Frames of a few lines and pools of more than eight strips fall back to a sweep per chroma plane; still exact."""
+    for fmt, w, h in (("YUV420P8", 512, 24), ("YUV420P8", 4096, 64), ("YUV422P8", 512, 12)):
         clip = clip_format(fmt, w, h)
         src = synth.frame(clip, "noise", seed=9)
         want = Oracle(oracle_cfg(clip, aa=48, aac=48)).process(src)
@@ -1519,78 +1519,34 @@ def test_geometries_the_one_sweep_form_does_not_take_keep_the_two_chroma_sweeps(
             assert same(want[p], got[p])
 
 
+UV_422 = [(256, 32), (512, 320), (992, 360), (1024, 180), (1920, 540), (3840, 64), (3840, 1080)]
+
+
 @pytest.mark.gpu
-def test_chaining_contexts_next_to_a_context_that_fills_the_device(hip_lib):
-    """The reference's concurrency model (MT_MULTI_INSTANCE, SangNom2.h:63-66) on the chains: four threads, each with a
-    context of its own, run a history-carrying 720x480 YUV420P8 clip as chains of 64 frames over EIGHT workgroups per cost
-    buffer (72 workgroups that wait for each other around a ring), while a fifth context keeps launching 512-frame 2160p
-    sweeps on its own stream -- more workgroups than the device holds at a time.  A chain workgroup that is not scheduled
-    next to its neighbour in time gives up and the launch is redone on one workgroup per buffer (chain_redone); either way
-    every frame equals its oracle instance and no call fails."""
-    import threading
+@pytest.mark.parametrize("w,h", UV_422, ids=[f"{w}x{h}" for w, h in UV_422])
+def test_u_and_v_as_one_sweep_for_422(hip_lib, w, h):
+    """4:2:2: the chroma planes are as tall as luma, so the shared pool has no row below their last one -- the U pass has no
+    extra row and V's last row takes nothing from it -- and the dependency cone covers most of the stale region for most of
+    the sweep (the waves right of the region stay to the end).  Against the oracle and the two-sweep form."""
     import torch
-    clip = clip_format("YUV420P8", 720, 480)
-    kw = dict(aa=48, aac=48)
-    T, N, LAUNCHES = 4, 64, 3
+    clip = clip_format("YUV422P8", w, h)
     dev = torch.device("cuda:0")
-    frames = [[synth.frame(clip, "noise" if (t + f) % 5 else "edges", seed=1000 * t + f) for f in range(N * LAUNCHES)] for t in range(T)]
-    want = []
-    for t in range(T):
+    for kw, parity, pattern in ((dict(order=1, aa=48, aac=48), [1, 1], "noise"), (dict(order=0, aa=128, aac=128), [0, 1], "edges"),
+                                (dict(order=2, aa=10, aac=20, dh=True), [1, 1], "checker")):
+        frames = [synth.frame(clip, pattern, seed=5 * w + h + i) for i in range(2)]
         ora = Oracle(oracle_cfg(clip, **kw))
-        want.append([ora.process(fr) for fr in frames[t]])
-    got = [[None] * (N * LAUNCHES) for _ in range(T)]
-    redone = [0] * T
-    errors = []
-    stop = threading.Event()
-
-    def chains(t):
-        try:
-            with SangNom2(clip, max_batch=N, chain=8, **kw) as flt:
-                for launch in range(LAUNCHES):
-                    part = frames[t][launch * N:(launch + 1) * N]
-                    src = [torch.from_numpy(np.stack([fr[p] for fr in part])).pin_memory().to(dev) for p in range(3)]
-                    dst = [torch.zeros((N,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(3)]
-                    torch.cuda.synchronize()
-                    flt.process_batch(src, dst)
-                    flt.synchronize()
-                    host = [to_host(d) for d in dst]
-                    for f in range(N):
-                        got[t][launch * N + f] = [host[p][f] for p in range(3)]
-                info = flt.info()
-                assert info.chained_frames == N * LAUNCHES
-                redone[t] = int(info.chain_redone)
-        except Exception as e:  # noqa: BLE001
-            errors.append((t, repr(e)))
-
-    def sweeps():
-        try:
-            big = clip_format("Y8", 3840, 2160)
-            M = 512
-            with SangNom2(big, max_batch=M, aa=48) as flt:
-                g = torch.Generator(device=dev)
-                g.manual_seed(5)
-                src = [torch.randint(0, 256, (M, 2160, 3840), device=dev, generator=g, dtype=torch.uint8)]
-                dst = [torch.empty_like(src[0])]
+        want = [ora.process(fr, parity=parity[i]) for i, fr in enumerate(frames)]
+        src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).pin_memory().to(dev) for p in range(3)]
+        got = {}
+        for name, extra in (("one", {}), ("two", dict(chroma_sweeps=1))):
+            with SangNom2(clip, max_batch=2, mode="fused", **kw, **extra) as flt:
+                dst = [torch.zeros((2,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(3)]
                 torch.cuda.synchronize()
-                while not stop.is_set():
-                    for _ in range(4):
-                        flt.process_batch(src, dst)
-                    flt.synchronize()
-        except Exception as e:  # noqa: BLE001
-            errors.append(("sweeps", repr(e)))
-
-    bg = threading.Thread(target=sweeps)
-    bg.start()
-    ths = [threading.Thread(target=chains, args=(t,)) for t in range(T)]
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    stop.set()
-    bg.join()
-    assert not errors, errors
-    for t in range(T):
-        for f in range(N * LAUNCHES):
+                flt.process_batch(src, dst, parity=parity)
+                flt.synchronize()
+                assert flt.info().uv_sweeps == (1 if name == "one" else 0)
+                got[name] = [to_host(d) for d in dst]
+        for f in range(2):
             for p in range(3):
-                assert same(want[t][f][p], got[t][f][p]), f"thread {t} frame {f} plane {p} (launches redone: {redone})"
-    print("chain launches redone per context:", redone)
+                assert same(want[f][p], got["one"][p][f]), f"{kw} frame {f} plane {p}: " + describe_diff(want[f][p], got["one"][p][f])
+                assert np.array_equal(got["one"][p][f], got["two"][p][f])

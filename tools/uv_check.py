@@ -11,11 +11,17 @@ from avisynth_sangnom2_amd import SangNom2, clip_format, synth  # noqa: E402
 
 GEOS = [(512, 64), (512, 640), (992, 720), (1024, 720), (544, 400), (1472, 1000), (1920, 1080), (1280, 720), (2560, 1440), (3840, 2160),
         (256, 64), (640, 48), (3840, 32), (2048, 1080), (3200, 1800), (960, 540 // 4 * 4)]
-if len(sys.argv) > 1:
-    GEOS = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+FMT = "YUV420P8"
+args = sys.argv[1:]
+if args and not args[0][0].isdigit():
+    FMT, args = args[0], args[1:]  # e.g. YUV422P8
+if args:
+    GEOS = [tuple(int(v) for v in a.split("x")) for a in args]
 bad = 0
 for w, h in GEOS:
-    clip = clip_format("YUV420P8", w, h)
+    if FMT == "YUV422P8":
+        h = max(16, h // 2)
+    clip = clip_format(FMT, w, h)
     for pattern, kw in (("noise", dict(aa=48, aac=48)), ("edges", dict(aa=128, aac=128)), ("noise", dict(aa=10, aac=0, order=2))):
         src = synth.frame(clip, pattern, seed=w + h)
         outs, uv = {}, {}
