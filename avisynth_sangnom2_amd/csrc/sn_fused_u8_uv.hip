@@ -14,13 +14,16 @@
 //     the U pass produced for row r + 1 in the same columns -- the O of the SAME lane one step earlier.  The U -> V hand-off
 //     never leaves the registers: no second pool, no LDS ring, no wait between the passes;
 //   * waves whose columns all lie right of the region (class S) have no lines, no stage 1, no stage 3: per buffer they
-//     fetch the luma pass's row (U half), merge last step's O (V half) with one v_perm per register, and smooth -- 69
-//     instructions per buffer where a region wave needs 101 plus lines and stage 3 -- and they LEAVE the workgroup when
-//     their first column falls out of the cone (it only shrinks: three columns per row; both passes' cones coincide at a
-//     step because the skew is two rows and the luma hand-off's cone is six columns wider);
+//     fetch the luma pass's row (U half; a whole step ahead), merge last step's O (V half) with one v_perm per register,
+//     and smooth -- 66-69 instructions per buffer, 623 per step where a region wave needs 1 063 -- and they LEAVE the
+//     workgroup when their first column falls out of the cone (it only shrinks: three columns per row; both passes' cones
+//     coincide at a step because the skew is two rows and the luma hand-off's cone is six columns wider);
 //   * waves inside the region (class R) run the plain sweep's row body on both passes at once; the one wave that holds
-//     the region's right edge (class RS) does both: lines and costs where its lanes are chroma, stale values where they
-//     are not (per-lane v_perm selectors, last step's O parked in LDS);
+//     the region's right edge (class RS; two when the region ends on a seam) does both: lines and costs where its lanes
+//     are chroma, stale values where they are not (per-lane v_perm selectors, last step's O parked in LDS).  Each class is
+//     a function of its own (sweep_entry, not inlined): no branch inside a buffer step, no spill in any row loop;
+//   * 4:2:0 and 4:2:2 alike (4:2:2: the pool has no row below the chroma planes' last one, so U has no extra row and V's
+//     last row takes nothing from it);
 //   * the first kSkew steps (V not started) and the last kSkew + 1 (U finished; the rows below the region, where stale
 //     values enter every column) run a masked variant of the step; everything between is branch-free per buffer.
 // Seams between strips, ghost lanes, the mailbox every K rows: as in sn_fused_u8_v3.hip -- one strip per wave here, so a
@@ -92,10 +95,7 @@ struct Step {
     unsigned omask;           // MASKED: halves whose O counts (the V half before its first row gives zero)
     unsigned amask;           // MASKED: halves whose D enters the next state (the U half of its last step keeps O alone)
     bool from_a;              // MASKED: the V half's stale value is the U half of A (left there by amask one step earlier)
-    int keep_lo, keep_hi;     // per lane: voffsets of the kept-line copies of this step (out of range: none)
-    int put_lo, put_hi;       // per lane: voffsets of the interpolated lines
-    int keep_row[2], put_row[2];  // their row offsets in dst
-    int slot_c, slot_n, slot_p;   // line park slots: above / below the interpolated line; where this step's new line goes
+    int slot_c, slot_n;       // line park slots of the lines above / below the interpolated one
 };
 
 struct Ctx {
