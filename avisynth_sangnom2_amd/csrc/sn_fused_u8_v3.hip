@@ -50,9 +50,11 @@ using namespace v3c;
 __device__ unsigned long long sn_row_cycles[8];
 #define SN_RT(k)                                                       \
     do {                                                               \
+        __builtin_amdgcn_sched_barrier(0); /* no instruction of one phase is scheduled into another */ \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
         rt_acc[k] += now_ - rt_last;                                   \
         rt_last = now_;                                                \
+        __builtin_amdgcn_sched_barrier(0);                             \
     } while (0)
 #else
 #define SN_RT(k) do { } while (0)
@@ -852,7 +854,7 @@ static hipError_t launch_mode(hipStream_t st, const v3::Args& a, int nframes)
     return hipGetLastError();
 }
 
-#if defined(SN_TU_PLAIN) && defined(SN_ROW_TIMING)
+#if defined(SN_ROW_TIMING) && (defined(SN_TU_PLAIN) || defined(SN_ROW_TIMING_COUPLED))  // (one of the two objects of this file carries the counters)
 extern "C" __attribute__((visibility("default"))) int sn_debug_row_cycles(unsigned long long out[8], int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return 1;

@@ -21,6 +21,29 @@ NAMES = ("wait for the prefetched line", "unpack, windows, park, kept-line store
          "ghost refresh + row set-up", "nine buffer steps + stage 3 + store", "publish (every 5th row)", "turn-taking / loop")
 
 dev = torch.device("cuda:0")
+if os.environ.get("SN_ROW_TIMING_COUPLED"):
+    # the library's OTHER object of sn_fused_u8_v3.hip carries the counters (-DSN_ROW_TIMING -DSN_ROW_TIMING_COUPLED for
+    # sn_fused_u8_v3.o): the luma sweep of a 4:2:0 clip (kLumaSpill); U and V run in sn_fused_u8_uv.hip and are not counted
+    clip = clip_format("YUV420P8", 3840, 2160)
+    n = 512
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    src = [torch.randint(0, 256, (n, 2160 >> (1 if p else 0), 3840 >> (1 if p else 0)), device=dev, generator=g, dtype=torch.uint8) for p in range(3)]
+    dst = [torch.empty_like(t) for t in src]
+    with SangNom2(clip, max_batch=n, aa=48, aac=48) as flt:
+        flt.process_batch(src, dst)
+        flt.synchronize()
+        out = (ctypes.c_ulonglong * 8)()
+        assert lib.sn_debug_row_cycles(ctypes.byref(out), 1) == 0
+        flt.process_batch(src, dst)
+        flt.synchronize()
+        assert lib.sn_debug_row_cycles(ctypes.byref(out), 1) == 0
+    rows = max(out[7], 1)
+    tot = sum(out[k] for k in range(7))
+    print(f"2160p-YUV420P8 luma sweep (kLumaSpill): {n} frames; {rows} wave-rows, {tot / rows:.0f} s_memtime ticks per wave-row")
+    for k in range(7):
+        print(f"    [{k}] {NAMES[k]:52s} {out[k] / rows:8.1f}  {100.0 * out[k] / tot:5.1f} %")
+    sys.exit(0)
 for wl, (w, h, n) in {"1080p-Y8": (1920, 1080, 2048), "2160p-Y8": (3840, 2160, 1024), "4320p-Y8": (7680, 4320, 256)}.items():
     if len(sys.argv) > 1 and wl not in sys.argv[1:]:
         continue
