@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         constexpr bool S1 = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
         constexpr bool STORE = decltype(store_tag)::value;
-        turns.update();
+        turns.update((r - 1) % K);
         Raw qnext = qn;
         if constexpr (S1) {
             if constexpr (gather_stage3(MODE)) {
@@ -987,7 +987,7 @@ hipError_t launch_fused_u16_v3(hipStream_t st, const PlaneArgs& p, double thresh
     a.nl = a.w / v3c::PXL;
     a.nvw = v3c::strips_for(a.nl);
     a.nw = a.nvw;
-    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
+    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw), 2);
     a.nframes = nframes;
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);

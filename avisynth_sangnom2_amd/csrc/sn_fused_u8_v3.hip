@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
         constexpr bool HAS_NEXT = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
         constexpr bool STORE = decltype(store_tag)::value;
-        turns.update();
+        turns.update((r - 1) % K);
         SN_RT(6);
         Raw qnext = qn;
         if constexpr (HAS_NEXT) {
@@ -931,7 +931,7 @@ hipError_t launch_fused_u8_v3(hipStream_t st, const PlaneArgs& p, double thresho
     a.src_bytes = (int)((int64_t)p.src_pitch * p.h_in);
     a.dst_bytes = (int)((int64_t)p.dst_pitch * p.h_out);
 
-    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw));
+    a.turn_shift = v3c::turn_shift_for(a.nk, a.nw * v3c::group_of(a.nw), 1);
     a.nframes = nframes;
     if (!pool) return launch_fused_u8_v3_plain(st, a, nframes, v3::kPlain);
     if (pool->nbands > 1) {

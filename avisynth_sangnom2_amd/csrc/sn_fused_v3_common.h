@@ -198,15 +198,31 @@ __device__ __forceinline__ unsigned bfi(unsigned m, unsigned x, unsigned y) { re
 // of a sweep measured best (short ones cost throughput); the slice length comes from the host.
 struct TurnTaking {
     unsigned slot_parity;
-    int shift;
+    int shift;  // > 0: time slices of 2^shift ticks of the 100 MHz clock; kLadder: by rows since the last seam barrier; 0: off
+    static constexpr int kLadder = -1;
     __device__ __forceinline__ void init(int turn_shift)
     {
         slot_parity = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u;  // HW_REG_HW_ID, wave_id bit 0
         shift = turn_shift;
     }
-    __device__ __forceinline__ void update() const  // once per row: a few scalar instructions
+    // once per row: a few scalar instructions.  `block_row`: rows this wave has done since the last seam barrier (0 .. K - 1).
+    __device__ __forceinline__ void update(int block_row) const
     {
         if (shift == 0) return;
+        if (shift == kLadder) {
+            // Workgroups of eight waves: the two waves a SIMD holds belong to the SAME workgroup and meet at its seam barrier.
+            // The priority FALLS with the rows done since that barrier -- 3, 3, 2, 1, 0 -- so whichever of the two is behind
+            // has the higher one and they reach the next barrier together.  No communication: the barrier itself is the
+            // common clock (see turn_shift_for).
+            switch (block_row) {
+            case 0:
+            case 1: __builtin_amdgcn_s_setprio(3); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 3: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+            }
+            return;
+        }
         const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> shift) & 1u;
         if (turn != slot_parity) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
@@ -227,13 +243,17 @@ __host__ __device__ constexpr int group_of(int nw) { return nw == 1 ? 4 : nw == 
 // of five rows: tools/row_timing.py (s_memtime around the phases of a row) finds a 4320p wave waiting at the seam barrier
 // for 22 % of its cycles (2160p, two workgroups per CU: 4 %) -- equal priorities are served oldest first, so wave k issues
 // whenever it can, reaches the barrier early and waits, and wave k + 4 then finishes the block alone at a single wave's
-// issue rate.  Removing the barrier gains nothing (the kernel is as slow as its slowest wave); taking turns in SHORT slices
-// does: 2^10 ticks = 10 us (two to three rows) measured best -- 4320p Y8 +3.3 %, 2160p Y16 +3.6 %, Y32 +1 %; 5 us +2 %,
-// 20 us +1 %, 40 us and more -1 % (profiles/r4_ab_experiments.md 3.).  A progress-based variant (each wave leaves its row
-// number in LDS, the one behind takes the priority) reached the same +3 % at 4320p and cost the one-sweep chroma passes 1 %.
-inline int turn_shift_for(int nk, int waves)
+// issue rate.  Removing the barrier gains nothing (the kernel is as slow as its slowest wave); keeping the pair in step
+// does.  Measured at 4320p Y8 (profiles/r4_ab_experiments.md 3., 7., 8.): time slices of 10 us +3.3 % (5 us +2 %, 20 us +1 %,
+// 40 us and more -1 %); row numbers exchanged through LDS, the wave behind takes the priority: +2.9 %; the same by buffer
+// steps: -19 % (nine LDS round trips per row); and what ships -- TurnTaking::kLadder, a priority that falls with the rows done
+// since the last barrier, which needs no exchange at all because the barrier is the pair's common clock: **+8.3 %** (8-bit
+// only: 2160p Y16 +0.8 % over the slices, YUV420P16 -1 %, Y32 and YUV444PS -7 %: those keep the slices of 10 us).
+inline int turn_shift_for(int nk, int waves, int bytes_per_sample)
 {
-    if (waves == 8) return 10;
+    // (the ladder is for the 8-bit sweep, whose rows are all but pure vector arithmetic; the float sweep, which moves three
+    // buffers' state through LDS in every row, loses 7 % with it and the 16-bit sweep gains nothing over the slices)
+    if (waves == 8) return bytes_per_sample == 1 ? TurnTaking::kLadder : 10;
     if (waves != 4) return 0;
     int s = 10;
     while ((128ll * nk) >> (s + 1)) ++s;
