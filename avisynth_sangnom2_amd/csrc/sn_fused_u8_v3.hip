@@ -720,20 +720,25 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u8_v3(Args 
                     } else {
                         // wave NW-1, right seam lanes: low half (strip NW-1) -> high half of wave 0's left ghosts;
                         // wave 0, left seam lanes: high half (strip NW) -> low half of wave NW-1's right ghosts
-                        unsigned short* to = pub_right ? mb.at(wpar, 0, 0, slot) + 1 : mb.at(wpar, NW - 1, 1, slot);
-                        const int sh = pub_right ? 0 : 16;
-                        auto send = [&](int b, const unsigned (&Ab)[PXL]) {
+                        // (two branches with the half fixed at compile time: the high half goes out with ds_write_b16_d16_hi, no
+                        // shift -- a per-lane shift amount cost 72 v_lshrrev per publish in the two waves the others wait for)
+                        auto send_half = [&](unsigned short* to, auto hi_tag) {
+                            constexpr bool HI = decltype(hi_tag)::value;
+                            auto send = [&](int b, const unsigned (&Ab)[PXL]) {
 #pragma unroll
-                            for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * 2] = (unsigned short)(Ab[j] >> sh);
+                                for (int j = 0; j < PXL; ++j) to[(b * PXL + j) * 2] = HI ? (unsigned short)(Ab[j] >> 16) : (unsigned short)Ab[j];
+                            };
+#pragma unroll
+                            for (int b = 0; b < kRegBuffers; ++b) send(b, A[b]);
+#pragma unroll
+                            for (int b = kRegBuffers; b < kBuffers; ++b) {
+                                unsigned t[PXL];
+                                load_A(parked, tid, b, t);
+                                send(b, t);
+                            }
                         };
-#pragma unroll
-                        for (int b = 0; b < kRegBuffers; ++b) send(b, A[b]);
-#pragma unroll
-                        for (int b = kRegBuffers; b < kBuffers; ++b) {
-                            unsigned t[PXL];
-                            load_A(parked, tid, b, t);
-                            send(b, t);
-                        }
+                        if (pub_right) send_half(mb.at(wpar, 0, 0, slot) + 1, std::integral_constant<bool, false>{});
+                        else send_half(mb.at(wpar, NW - 1, 1, slot), std::integral_constant<bool, true>{});
                     }
                 }
             }
