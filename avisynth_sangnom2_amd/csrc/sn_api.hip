@@ -672,7 +672,8 @@ static int check_planes(Context* c, const void* const src[3], const int32_t sp[3
 // 4320p, where launches of 16 .. 32 frames took the sweeps at up to twice the pool path's time.
 //   sweep: rows x t_row; t_row = 2.6 us (8-bit; 3.8 us for planes of more than eight strips: eight waves), 2.8 us (16-bit),
 //          4.3 us (float); the chroma planes of a coupled 4:2:0 clip sweep the luma-wide pool: 8-bit U and V as one sweep
-//          3.8 us per chroma row for both, otherwise 3.15 us (16-bit) / 4.7 us (float) per row and plane
+//          3.8 us per chroma row for both (1.9 us booked to each plane), otherwise 3.0 us (8-bit) / 3.15 us (16-bit) / 4.7 us
+//          (float) per row and plane
 //   pool : bh x (a + 0.036 us x ceil(stride / 1024)) + 60 us + n x stride x bh x per_elem per processed plane;
 //          a = 0.25 / 0.22 / 0.33 us, per_elem = 12.9 / 19.4 / 32.6 ps for 8-bit / 16-bit / float
 static bool prefer_pool(const Context* c, int n, int slot0)
