@@ -144,7 +144,7 @@ class SangNom2:
         return out
 
     def set_policy(self, **fields) -> None:
-        """Change the scheduling policy of the live context (sn_set_policy): small_launches, chain, copy_threads."""
+        """Change the scheduling policy of the live context (sn_set_policy): small_launches, chain, copy_threads, chroma_sweeps."""
         cur = capi.SnPolicy(struct_size=ctypes.sizeof(capi.SnPolicy))
         self._check(self._lib.sn_get_policy(self._h, ctypes.byref(cur)))
         for k, v in fields.items():

@@ -156,7 +156,7 @@ int sn_create(const sn_config* cfg, sn_context** out);
 int sn_create_with_policy(const sn_config* cfg, const sn_policy* policy /* NULL = defaults */, sn_context** out);
 void sn_destroy(sn_context* ctx);
 
-/* The policy in force / a new one (small_launches, chain and copy_threads may change during a context's life; the
+/* The policy in force / a new one (small_launches, chain, copy_threads and chroma_sweeps may change during a context's life; the
  * scratch budget is fixed at creation and ignored here). */
 int sn_get_policy(sn_context* ctx, sn_policy* policy);
 int sn_set_policy(sn_context* ctx, const sn_policy* policy);

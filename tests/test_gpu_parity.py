@@ -1550,3 +1550,33 @@ def test_u_and_v_as_one_sweep_for_422(hip_lib, w, h):
             for p in range(3):
                 assert same(want[f][p], got["one"][p][f]), f"{kw} frame {f} plane {p}: " + describe_diff(want[f][p], got["one"][p][f])
                 assert np.array_equal(got["one"][p][f], got["two"][p][f])
+
+
+@pytest.mark.gpu
+def test_chroma_sweeps_can_change_during_a_contexts_life(hip_lib):
+    """sn_set_policy(chroma_sweeps): a context that starts with U and V as one sweep holds the luma -> U pool only; switching to a
+    sweep per plane allocates the U -> V pool on first use, switching back leaves it idle.  Same bytes every time."""
+    import torch
+    clip = clip_format("YUV420P8", 1024, 360)
+    dev = torch.device("cuda:0")
+    kw = dict(aa=48, aac=48)
+    frames = [synth.frame(clip, "noise", seed=40 + i) for i in range(4)]
+    ora = Oracle(oracle_cfg(clip, **kw))
+    want = [ora.process(fr) for fr in frames]
+    src = [torch.from_numpy(np.stack([fr[p] for fr in frames])).pin_memory().to(dev) for p in range(3)]
+    with SangNom2(clip, max_batch=4, mode="fused", **kw) as flt:
+        for sweeps, uv_before, uv_after in ((1, 0, 0), (0, 0, 1), (1, 1, 1), (0, 1, 1)):
+            flt.set_policy(chroma_sweeps=sweeps)
+            assert flt.get_policy().chroma_sweeps == sweeps
+            assert flt.info().uv_sweeps == uv_before
+            dst = [torch.zeros((4,) + flt.plane_shape_out(p), dtype=torch.uint8, device=dev) for p in range(3)]
+            torch.cuda.synchronize()
+            flt.process_batch(src, dst)
+            flt.synchronize()
+            assert flt.info().uv_sweeps == uv_after
+            for f in range(4):
+                for p in range(3):
+                    assert same(want[f][p], to_host(dst[p][f])), f"chroma_sweeps={sweeps} frame {f} plane {p}"
+        if True:  # the U -> V hand-off exists now (the two-sweep form ran): readable, and not all zero inside the cone
+            rows = flt.read_coupled_rows(1)
+            assert rows.any()
