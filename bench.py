@@ -38,6 +38,7 @@ WORKLOADS = {
     "2160p-YUV420P8": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48)),
     "2160p-YUV420P8-isolated": ("YUV420P8", 3840, 2160, dict(order=1, aa=48, aac=48, isolated_planes=True)),
     "2160p-YUV422P8": ("YUV422P8", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "1080p-YUV420P8": ("YUV420P8", 1920, 1080, dict(order=1, aa=48, aac=48)),
     "480p-YUV420P8": ("YUV420P8", 720, 480, dict(order=1, aa=48, aac=48)),  # width % 32 != 0: history-carrying
     "480p-YUV420P8-fresh": ("YUV420P8", 720, 480, dict(order=1, aa=48, aac=48, fresh_pool=True)),
     "480p-YUV420P16": ("YUV420P16", 720, 480, dict(order=1, aa=48, aac=48)),  # the 16-bit and float chains
