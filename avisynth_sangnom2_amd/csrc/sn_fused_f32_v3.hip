@@ -179,6 +179,7 @@ struct PoolIO {
 struct RowCtx {
     int r;
     int vin;       // chroma modes: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
+    int vin_next;  // ... and of row r + 2
     int vout;      // voffset of this row's stores (out of range: not kept)
     bool any_out;  // wave-uniform: some lane of this wave stores in this row
 };
@@ -203,6 +204,7 @@ __device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL],
         io.finish(stale, D);
         __builtin_amdgcn_sched_barrier(0);  // the next fetch goes into the registers this one has just left
         if constexpr (I + 1 < kBuffers) stale = io.issue(visit(I + 1), rc.r + 1, rc.vin);
+        else stale = io.issue(visit(0), rc.r + 2, rc.vin_next);  // the next row's first buffer: the fetch never starts a row late
         if constexpr (S1) {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) D[j] = role.inside_b ? cost<BUF>(n, nn, j) : D[j];
@@ -295,8 +297,9 @@ struct Out {
 // S3: the row has an interpolated line (stage 3); a chroma sweep covers rows below its plane without one.
 template <bool S1, bool S3, int MODE, int NT>
 __device__ __forceinline__ Out row_step(float (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk, int tid, const Line& n,
-                                        const Line& nn, const LaneRole& role, float aaf, const PoolIO& io, const RowCtx& rc)
+                                        const Line& nn, const LaneRole& role, float aaf, const PoolIO& io, const RowCtx& rc, PoolIO::RawPair& stale)
 {
+    // stale (chroma modes): the previous pass's row r + 1 of the first buffer, in flight since the last step of the row before
     constexpr int kRegBuffers = reg_buffers(MODE);
     float vmin[PXL];
     unsigned rank[PXL];
@@ -305,8 +308,6 @@ __device__ __forceinline__ Out row_step(float (&A)[reg_buffers(MODE)][PXL], cons
         vmin[j] = __builtin_inff();
         rank[j] = 0u;
     }
-    PoolIO::RawPair stale{};
-    if constexpr (chroma_mode(MODE)) stale = io.issue(visit(0), rc.r + 1, rc.vin);
     auto run = [&](auto idx) {
         constexpr int I = decltype(idx)::value;
         constexpr int B = visit(I);
@@ -502,10 +503,21 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
             const int v1 = (a.rows_in >= 1 && in_cone(1, a.cone_in)) ? io.v_a : kOutOfRange;
 #pragma unroll
             for (int b = 0; b < kBuffers; ++b) io.finish(io.issue(b, 1, v1), As[b]);
+            // the stale rows are fetched a whole row ahead (one row of nine buffers is 72 registers; a buffer's slot is refilled as soon
+            // as its step has taken the values out): two steps ahead, as until round 4, was less than the trip to memory
+            PoolIO::RawPair ahead[kBuffers];
+            {
+                const int v2 = (a.rows_in >= 2 && in_cone(2, a.cone_in)) ? io.v_a : kOutOfRange;
+#pragma unroll
+                for (int b = 0; b < kBuffers; ++b) ahead[b] = io.issue(b, 2, v2);
+            }
             for (int r = 1; r <= sweep; ++r) {
+#ifdef SN_X_BALANCED  // DIAGNOSTIC (wrong results): every stale wave lives 5/9 of the sweep, the load of a balanced hand-over
+                if (r > sweep * 5 / 9) return;
+#else
                 if (x_wave >= a.cone_w + 3 * (a.cone_nr - (r - 1) + 2) + a.cone_in) return;  // outside for good
-                const int vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
-                PoolIO::RawPair s0 = io.issue(0, r + 1, vin), s1 = io.issue(1, r + 1, vin);
+#endif
+                const int vin = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
                 if (r > 1 && (r - 1) % K == 0) {
                     __syncthreads();
                     if (recv) {
@@ -518,22 +530,21 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
                 }
                 const int vout = (r <= a.rows_out && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
                 const bool vout_any = __builtin_amdgcn_readfirstlane(__any(vout != kOutOfRange) ? 1 : 0) != 0;
-                stale_buffer_step<0>(As[0], s0, role, io, r, vout, vout_any);
-                s0 = io.issue(2, r + 1, vin);
-                stale_buffer_step<1>(As[1], s1, role, io, r, vout, vout_any);
-                s1 = io.issue(3, r + 1, vin);
-                stale_buffer_step<2>(As[2], s0, role, io, r, vout, vout_any);
-                s0 = io.issue(4, r + 1, vin);
-                stale_buffer_step<3>(As[3], s1, role, io, r, vout, vout_any);
-                s1 = io.issue(5, r + 1, vin);
-                stale_buffer_step<4>(As[4], s0, role, io, r, vout, vout_any);
-                s0 = io.issue(6, r + 1, vin);
-                stale_buffer_step<5>(As[5], s1, role, io, r, vout, vout_any);
-                s1 = io.issue(7, r + 1, vin);
-                stale_buffer_step<6>(As[6], s0, role, io, r, vout, vout_any);
-                s0 = io.issue(8, r + 1, vin);
-                stale_buffer_step<7>(As[7], s1, role, io, r, vout, vout_any);
-                stale_buffer_step<8>(As[8], s0, role, io, r, vout, vout_any);
+                auto run = [&](auto buf) {
+                    constexpr int B = decltype(buf)::value;
+                    const PoolIO::RawPair cur = ahead[B];
+                    ahead[B] = io.issue(B, r + 2, vin);
+                    stale_buffer_step<B>(As[B], cur, role, io, r, vout, vout_any);
+                };
+                run(std::integral_constant<int, 0>{});
+                run(std::integral_constant<int, 1>{});
+                run(std::integral_constant<int, 2>{});
+                run(std::integral_constant<int, 3>{});
+                run(std::integral_constant<int, 4>{});
+                run(std::integral_constant<int, 5>{});
+                run(std::integral_constant<int, 6>{});
+                run(std::integral_constant<int, 7>{});
+                run(std::integral_constant<int, 8>{});
                 if (r < sweep && r % K == 0) {
                     if (pub_right || pub_left) {
                         unsigned* to = pub_right ? mb.at(((r + 1) / K) & 1, wave + 1, 0, slot) : mb.at(((r + 1) / K) & 1, wave - 1, 1, slot);
@@ -598,6 +609,8 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     Raw qn = r0 + 1 <= nr ? load_raw(src_next) : q1;
     src_next += src_step;
 
+    PoolIO::RawPair stale_next{};
+    if constexpr (chroma_mode(MODE)) stale_next = io.issue(visit(0), r0 + 1, (r0 + 1 <= a.rows_in && in_cone(r0 + 1, a.cone_in)) ? io.v_a : kOutOfRange);
     TurnTaking turns;
     turns.init(a.turn_shift);
     auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
@@ -636,12 +649,17 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         rc.r = r;
         rc.vin = rc.vout = kOutOfRange;
         rc.any_out = false;
+        rc.vin_next = kOutOfRange;
+        if constexpr (chroma_mode(MODE)) rc.vin_next = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
         if constexpr (chroma_mode(MODE)) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+#ifdef SN_X_REGION_NOSTALE  // DIAGNOSTIC (wrong results): what do the stale loads of the region's ghost lanes cost?
+        rc.vin = kOutOfRange;
+#endif
         if constexpr (has_pools(MODE)) {
             rc.vout = (r <= a.rows_out && (!BAND || r >= ra) && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
         }
-        const Out o = row_step<S1, S3, MODE>(A, parked, tid, n, nn, role, aaf, io, rc);
+        const Out o = row_step<S1, S3, MODE>(A, parked, tid, n, nn, role, aaf, io, rc, stale_next);
         if constexpr (S3) put(out_row, o);
         out_row += dst_step;
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c

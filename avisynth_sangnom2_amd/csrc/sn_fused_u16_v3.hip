@@ -266,9 +266,22 @@ struct PoolIO {
     }
 };
 
+// Chroma modes, waves of the region: the previous pass's row r + 1 of buffer B + kStaleAhead is fetched while buffer B is
+// smoothed, and the last steps of a row fetch the first buffers of the next row's: the ring lives across rows (9 is a multiple
+// of its size, so a buffer's slot is the same in every row).  A fetch -- also one whose every lane is out of range, as in the
+// waves inside the region -- takes about 0.4 us under load, a step of a wave that has its SIMD to itself 0.3 us: one step
+// ahead and a fresh start in every row (until round 4) made every step wait.
+constexpr int kStaleAhead = 2;
+static_assert(kBuffers % (kStaleAhead + 1) == 0, "a buffer's slot in the ring must not depend on the row");
+struct StaleRing {
+    u32x4 s[kStaleAhead + 1];
+};
+
 struct RowCtx {
     int r;
     int vin;  // kChroma: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
+    int vin_next;  // ... and of row r + 2
+    bool any_in, any_in_next;  // wave-uniform: some lane of the wave fetches (row r + 1, row r + 2)
     int vout;
     bool any_out;  // wave-uniform: some lane of this wave stores in this row
     int slot_c, slot_n;  // gather modes: LDS slots of the lines above / below the interpolated one
@@ -276,7 +289,10 @@ struct RowCtx {
 
 // STORE: the luma sweep's smoothed row goes to pool_out (rows past the hand-off run a loop without the packing: no
 // branch inside a buffer step, see sn_fused_u8_v3.hip)
-template <int BUF, int MODE, bool S1, bool STORE>
+// FETCH (chroma modes): some lane of the wave takes the previous pass's value instead of a cost in this row.  A wave inside
+// the region (three of the four of a 4:2:0 pass) does not: its step is the one of a plane on its own -- v_sad_u16 accumulates,
+// D never exists -- and it fetches nothing (a fetch whose every lane is out of range is still a trip to the texture unit).
+template <int BUF, int MODE, bool S1, bool STORE, bool FETCH>
 __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)[PXL], const LineOf<MODE>& n, const LineOf<MODE>& nn,
                                             const LaneRole& role, const PoolIO& io, const RowCtx& rc, const u32x4& stale)
 {
@@ -298,6 +314,23 @@ __device__ __forceinline__ void buffer_step(unsigned (&A)[PXL], unsigned (&kmin)
             kmin[j] = umin(kmin[j], key);
         }
         if constexpr (has_pools(MODE) && STORE) io.store(BUF, rc.r, rc.vout, O);  // lanes that keep nothing: out-of-range voffset
+        return;
+    }
+    if constexpr (chroma_mode(MODE) && !FETCH) {
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) S[j] = S1 ? cost_acc<BUF>(n, nn, j, A[j]) : A[j];
+        box7(S, Bx, role);
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+            const unsigned t = Bx[j] & 0xffff0u;
+            O[j] = t >> 4;
+            A[j] = S1 ? cost_acc<BUF>(n, nn, j, O[j]) : O[j];
+            kmin[j] = umin(kmin[j], t | rank_of<BUF, MODE>());
+        }
+        if constexpr (MODE == kChroma) {
+            if (rc.any_out) io.store(BUF, rc.r, rc.vout, O);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one step at a time: interleaved, the steps of a row spill
         return;
     }
     if constexpr (chroma_mode(MODE)) {
@@ -406,30 +439,29 @@ struct Out {
     u32x4 v;  // 8 interpolated 16-bit pixels
 };
 
-template <int MODE, bool S1, bool S3, bool STORE, int NT>
+template <int MODE, bool S1, bool S3, bool STORE, bool FETCH, int NT>
 __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk,
                                         int tid, const LineOf<MODE>& n, const LineOf<MODE>& nn, const LaneRole& role, unsigned thr_key,
-                                        const PoolIO& io, const RowCtx& rc)
+                                        const PoolIO& io, const RowCtx& rc, StaleRing& st)
 {
     unsigned kmin[PXL];
 #pragma unroll
     for (int j = 0; j < PXL; ++j) kmin[j] = thr_key;  // the `minBuf > aaf` arm: cost aaf + 1, rank 0
-    u32x4 st0{}, st1{};
-    if constexpr (chroma_mode(MODE)) st0 = io.issue(0, rc.r + 1, rc.vin);
     auto run = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
-        if constexpr (chroma_mode(MODE)) {
-            if constexpr (B + 1 < kBuffers) st1 = io.issue(B + 1, rc.r + 1, rc.vin);
+        if constexpr (chroma_mode(MODE) && FETCH) {  // see StaleRing
+            constexpr int T = B + kStaleAhead;
+            if constexpr (T < kBuffers) st.s[T % (kStaleAhead + 1)] = io.issue(T, rc.r + 1, rc.vin);
+            else st.s[T % (kStaleAhead + 1)] = io.issue(T - kBuffers, rc.r + 2, rc.vin_next);
         }
         if constexpr (B < reg_buffers(MODE)) {
-            buffer_step<B, MODE, S1, STORE>(A[B], kmin, n, nn, role, io, rc, st0);
+            buffer_step<B, MODE, S1, STORE, FETCH>(A[B], kmin, n, nn, role, io, rc, st.s[B % (kStaleAhead + 1)]);
         } else {
             unsigned t[PXL];
             pk.load_A(tid, B, t);
-            buffer_step<B, MODE, S1, STORE>(t, kmin, n, nn, role, io, rc, st0);
+            buffer_step<B, MODE, S1, STORE, FETCH>(t, kmin, n, nn, role, io, rc, st.s[B % (kStaleAhead + 1)]);
             pk.store_A(tid, B, t);
         }
-        if constexpr (chroma_mode(MODE)) st0 = st1;
     };
     run(std::integral_constant<int, 0>{});
     run(std::integral_constant<int, 1>{});
@@ -440,6 +472,12 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
     run(std::integral_constant<int, 6>{});
     run(std::integral_constant<int, 7>{});
     run(std::integral_constant<int, 8>{});
+    if constexpr (chroma_mode(MODE) && !FETCH) {  // the next row fetches: its first buffers, as its own last steps would have
+        if (rc.any_in_next) {
+#pragma unroll
+            for (int b = 0; b < kStaleAhead; ++b) st.s[b] = io.issue(b, rc.r + 2, rc.vin_next);
+        }
+    }
 
     Out o{};
     if constexpr (!S3) return o;
@@ -765,9 +803,16 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     src_next += src_step;
 
     Out pending{};
+    StaleRing stale_ring{};
+    if constexpr (chroma_mode(MODE)) {  // the first row's first buffers
+        const int v = (r0 + 1 <= a.rows_in && in_cone(r0 + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+#pragma unroll
+        for (int b = 0; b < kStaleAhead; ++b) stale_ring.s[b] = io.issue(b, r0 + 1, v);
+    }
     TurnTaking turns;
     turns.init(a.turn_shift);
-    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag, auto store_tag) __attribute__((always_inline)) {
+    // fetch_tag (chroma modes): false for the rows in which no lane of this wave takes a stale value (buffer_step)
+    auto step = [&](int r, LineOf<MODE>& n, LineOf<MODE>& nn, auto s1_tag, auto s3_tag, auto store_tag, auto fetch_tag) __attribute__((always_inline)) {
         constexpr bool S1 = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
         constexpr bool STORE = decltype(store_tag)::value;
@@ -813,7 +858,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         RowCtx rc;
         rc.r = r;
         rc.vin = rc.vout = kOutOfRange;
-        if constexpr (chroma_mode(MODE)) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+        rc.vin_next = kOutOfRange;
+        if constexpr (chroma_mode(MODE)) {
+            rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+            rc.vin_next = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
+        }
+        rc.any_in = chroma_mode(MODE) && __builtin_amdgcn_readfirstlane(__any(rc.vin != kOutOfRange) ? 1 : 0) != 0;
+        rc.any_in_next = chroma_mode(MODE) && __builtin_amdgcn_readfirstlane(__any(rc.vin_next != kOutOfRange) ? 1 : 0) != 0;
         rc.any_out = false;
         rc.slot_c = (r - 1) % 3;
         rc.slot_n = r % 3;
@@ -821,7 +872,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
             rc.vout = (r <= a.rows_out && (!BAND || r >= ra) && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
         }
-        pending = row_step<MODE, S1, S3, STORE>(A, parked, tid, n, nn, role, thr_key, io, rc);
+        pending = row_step<MODE, S1, S3, STORE, chroma_mode(MODE) && decltype(fetch_tag)::value>(A, parked, tid, n, nn, role, thr_key, io, rc, stale_ring);
         if constexpr (S1 && !gather_stage3(MODE)) parked.park(tid, n);  // n is the next row's c
         if (r < sweep && r % K == 0) {
             const int wpar = ((r + 1) / K) & 1;
@@ -864,49 +915,58 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         using ST = std::integral_constant<bool, MODE == kLumaSpill>;
         int r = r0;
         for (; r < ra; ++r) {  // the run-up: nothing interpolated, nothing handed on
-            step(r, L1, L0, T{}, F{}, F{});
+            step(r, L1, L0, T{}, F{}, F{}, T{});
             L1 = L0;
         }
         leave_state(0);
         const int own_next = rb < nr ? rb + 1 : nr;
         for (; r < own_next; ++r) {
-            step(r, L1, L0, T{}, T{}, ST{});
+            step(r, L1, L0, T{}, T{}, ST{}, T{});
             L1 = L0;
         }
-        if (rb == nr) step(nr, L1, L0, F{}, T{}, ST{});
+        if (rb == nr) step(nr, L1, L0, F{}, T{}, ST{}, T{});
         else leave_state(1);
         put(out_row, pending);
     } else {
         // rows [from, to) with a following line pair: two rows per trip with the roles of the two line registers swapped
         // (no copy of a line per row); afterwards L1 is K[to] again
-        auto rows = [&](int from, int to, auto store_tag) __attribute__((always_inline)) {
+        auto rows = [&](int from, int to, auto store_tag, auto fetch_tag) __attribute__((always_inline)) {
             int r = from;
             for (; r + 1 < to; r += 2) {
-                step(r, L1, L0, T{}, T{}, store_tag);
-                step(r + 1, L0, L1, T{}, T{}, store_tag);
+                step(r, L1, L0, T{}, T{}, store_tag, fetch_tag);
+                step(r + 1, L0, L1, T{}, T{}, store_tag, fetch_tag);
             }
             if (r < to) {
-                step(r, L1, L0, T{}, T{}, store_tag);
+                step(r, L1, L0, T{}, T{}, store_tag, fetch_tag);
                 L1 = L0;
             }
         };
         if constexpr (MODE == kLumaSpill) {
             // the rows a chroma pass can see first, with the hand-off; the rest of the plane without
             const int split = a.rows_out + 1 < nr ? a.rows_out + 1 : nr;
-            rows(1, split, T{});
-            rows(split, nr, F{});
+            rows(1, split, T{}, T{});
+            rows(split, nr, F{}, T{});
             if (nr >= 1) {
-                step(nr, L1, L0, F{}, T{}, T{});
+                step(nr, L1, L0, F{}, T{}, T{}, T{});
                 put(out_row, pending);
             }
         } else {
-            rows(1, nr, F{});
+            int quiet = 1;  // rows [1, quiet): no lane of this wave takes a stale value (row r fetches pool row r + 1)
+            if constexpr (chroma_mode(MODE)) {
+                const int xa = (lane << 3) + wave * (kInner * PXL);
+                const int lim = a.cone_w + 3 * (a.cone_nr - 2 + 2) + a.cone_in;  // in_cone(2, cone_in), the widest row the loop fetches
+                const bool beyond = xa < (lim < a.w ? lim : a.w) && xa + PXL > a.cone_w;
+                if (!__builtin_amdgcn_readfirstlane(__any(beyond) ? 1 : 0)) quiet = nr < a.cone_nr ? nr : a.cone_nr;
+                if (quiet < 1) quiet = 1;
+            }
+            rows(1, quiet, F{}, F{});
+            rows(quiet, nr, F{}, T{});
             if (nr >= 1) {
-                step(nr, L1, L0, F{}, T{}, F{});
+                step(nr, L1, L0, F{}, T{}, F{}, T{});
                 put(out_row, pending);
             }
             if constexpr (chroma_mode(MODE)) {
-                for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{}, F{});
+                for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{}, F{}, T{});
             }
         }
     }
