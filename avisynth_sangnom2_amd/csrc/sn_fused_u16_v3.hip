@@ -18,6 +18,26 @@
 namespace sn {
 namespace w16 {
 
+#ifdef SN_WAVE_TIMING  // tools/wave_timing.py: per mode and wave index, shader-clock ticks in the kernel and at its barriers
+__device__ unsigned long long sn_wave_ticks[5][8][2];
+#define SN_SYNC()                                                      \
+    do {                                                               \
+        const unsigned long long wt_a = __builtin_amdgcn_s_memtime();  \
+        __syncthreads();                                               \
+        wt_barrier += __builtin_amdgcn_s_memtime() - wt_a;             \
+    } while (0)
+#define SN_WT_FLUSH()                                                                                         \
+    do {                                                                                                      \
+        if (lane == 0) {                                                                                      \
+            atomicAdd(&sn_wave_ticks[MODE][wave][0], __builtin_amdgcn_s_memtime() - wt_start);                \
+            atomicAdd(&sn_wave_ticks[MODE][wave][1], wt_barrier);                                             \
+        }                                                                                                     \
+    } while (0)
+#else
+#define SN_SYNC() __syncthreads()
+#define SN_WT_FLUSH() do {} while (0)
+#endif
+
 using namespace v3c;
 constexpr int kMaxWaves = 8;
 constexpr unsigned kVal = 0xffffu;
@@ -271,7 +291,7 @@ struct PoolIO {
 // of its size, so a buffer's slot is the same in every row).  A fetch -- also one whose every lane is out of range, as in the
 // waves inside the region -- takes about 0.4 us under load, a step of a wave that has its SIMD to itself 0.3 us: one step
 // ahead and a fresh start in every row (until round 4) made every step wait.
-constexpr int kStaleAhead = 2;
+constexpr int kStaleAhead = 8;
 static_assert(kBuffers % (kStaleAhead + 1) == 0, "a buffer's slot in the ring must not depend on the row");
 struct StaleRing {
     u32x4 s[kStaleAhead + 1];
@@ -281,7 +301,6 @@ struct RowCtx {
     int r;
     int vin;  // kChroma: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
     int vin_next;  // ... and of row r + 2
-    bool any_in, any_in_next;  // wave-uniform: some lane of the wave fetches (row r + 1, row r + 2)
     int vout;
     bool any_out;  // wave-uniform: some lane of this wave stores in this row
     int slot_c, slot_n;  // gather modes: LDS slots of the lines above / below the interpolated one
@@ -472,13 +491,6 @@ __device__ __forceinline__ Out row_step(unsigned (&A)[reg_buffers(MODE)][PXL], c
     run(std::integral_constant<int, 6>{});
     run(std::integral_constant<int, 7>{});
     run(std::integral_constant<int, 8>{});
-    if constexpr (chroma_mode(MODE) && !FETCH) {  // the next row fetches: its first buffers, as its own last steps would have
-        if (rc.any_in_next) {
-#pragma unroll
-            for (int b = 0; b < kStaleAhead; ++b) st.s[b] = io.issue(b, rc.r + 2, rc.vin_next);
-        }
-    }
-
     Out o{};
     if constexpr (!S3) return o;
     if constexpr (gather_stage3(MODE)) {
@@ -573,6 +585,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
     mb.h = reinterpret_cast<unsigned*>(parked.a + (kBuffers - RB) * 2 * NT);
     const int wave = tid >> 6;
     const int lane = tid & 63;
+#ifdef SN_WAVE_TIMING
+    const unsigned long long wt_start = __builtin_amdgcn_s_memtime();
+    unsigned long long wt_barrier = 0;
+#endif
 
     // lane -> column group: wave 0 owns lanes 0..61 (all 64 if it is the only wave), later waves own
     // lanes 2..61 (the last one up to 63); the other lanes are ghosts of the neighbouring wave
@@ -698,7 +714,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
                 if (x_wave >= a.cone_w + 3 * (a.cone_nr - (r - 1) + 2) + a.cone_in) return false;  // outside for good
                 fetch(r + 2, nxt);
                 if (r > 1 && (r - 1) % K == 0) {
-                    __syncthreads();
+                    SN_SYNC();
                     if (recv) {
                         const unsigned* from = mb.at((r / K) & 1, wave, lane < GH ? 0 : 1, slot);
 #pragma unroll
@@ -730,9 +746,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
                 return true;
             };
             for (int r = 1; r <= sweep; r += 2) {
-                if (!stale_row(r, sa, sb)) return;
-                if (r + 1 <= sweep && !stale_row(r + 1, sb, sa)) return;
+                if (!stale_row(r, sa, sb)) { SN_WT_FLUSH(); return; }
+                if (r + 1 <= sweep && !stale_row(r + 1, sb, sa)) { SN_WT_FLUSH(); return; }
             }
+            SN_WT_FLUSH();
             return;
         }
     }
@@ -804,11 +821,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
 
     Out pending{};
     StaleRing stale_ring{};
-    if constexpr (chroma_mode(MODE)) {  // the first row's first buffers
-        const int v = (r0 + 1 <= a.rows_in && in_cone(r0 + 1, a.cone_in)) ? io.v_a : kOutOfRange;
-#pragma unroll
-        for (int b = 0; b < kStaleAhead; ++b) stale_ring.s[b] = io.issue(b, r0 + 1, v);
-    }
     TurnTaking turns;
     turns.init(a.turn_shift);
     // fetch_tag (chroma modes): false for the rows in which no lane of this wave takes a stale value (buffer_step)
@@ -839,7 +851,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         }
         const int par = (r / K) & 1;
         if (r > r0 && (r - 1) % K == 0) {
-            __syncthreads();
+            SN_SYNC();
             if (recv) {
                 const unsigned* from = mb.at(par, wave, lane < GH ? 0 : 1, slot);
 #pragma unroll
@@ -863,8 +875,6 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
             rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
             rc.vin_next = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
         }
-        rc.any_in = chroma_mode(MODE) && __builtin_amdgcn_readfirstlane(__any(rc.vin != kOutOfRange) ? 1 : 0) != 0;
-        rc.any_in_next = chroma_mode(MODE) && __builtin_amdgcn_readfirstlane(__any(rc.vin_next != kOutOfRange) ? 1 : 0) != 0;
         rc.any_out = false;
         rc.slot_c = (r - 1) % 3;
         rc.slot_n = r % 3;
@@ -960,6 +970,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
                 if (quiet < 1) quiet = 1;
             }
             rows(1, quiet, F{}, F{});
+            if constexpr (chroma_mode(MODE)) {  // the ring's first fill: the first buffers of the first row that fetches
+                const int v = (quiet + 1 <= a.rows_in && in_cone(quiet + 1, a.cone_in)) ? io.v_a : kOutOfRange;
+#pragma unroll
+                for (int b = 0; b < kStaleAhead; ++b) stale_ring.s[b] = io.issue(b, quiet + 1, v);
+            }
             rows(quiet, nr, F{}, T{});
             if (nr >= 1) {
                 step(nr, L1, L0, F{}, T{}, F{}, T{});
@@ -976,7 +991,25 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         const Raw q = load_raw(src_line + (nk - 1) * src_step);
         keep((2 * nk - 1) * a.dst_pitch, q);
     }
+    SN_WT_FLUSH();
 }
+
+#ifdef SN_WAVE_TIMING
+}  // namespace w16
+}  // namespace sn
+extern "C" __attribute__((visibility("default"))) int sn_debug_wave_ticks(unsigned long long out[5 * 8 * 2], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sn::w16::sn_wave_ticks), 5 * 8 * 2 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        static const unsigned long long zero[5 * 8 * 2] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sn::w16::sn_wave_ticks), zero, sizeof zero) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace sn {
+namespace w16 {
+#endif
 
 template <int MODE, bool BAND = false>
 static hipError_t launch_mode(hipStream_t st, const Args& a, int nframes)
