@@ -28,6 +28,26 @@
 namespace sn {
 namespace f32 {
 
+#ifdef SN_WAVE_TIMING  // tools/wave_timing.py: per mode and wave index, shader-clock ticks in the kernel and at its barriers
+__device__ unsigned long long sn_wave_ticks[5][8][2];
+#define SN_SYNC()                                                      \
+    do {                                                               \
+        const unsigned long long wt_a = __builtin_amdgcn_s_memtime();  \
+        __syncthreads();                                               \
+        wt_barrier += __builtin_amdgcn_s_memtime() - wt_a;             \
+    } while (0)
+#define SN_WT_FLUSH()                                                                                         \
+    do {                                                                                                      \
+        if (lane == 0) {                                                                                      \
+            atomicAdd(&sn_wave_ticks[MODE][wave][0], __builtin_amdgcn_s_memtime() - wt_start);                \
+            atomicAdd(&sn_wave_ticks[MODE][wave][1], wt_barrier);                                             \
+        }                                                                                                     \
+    } while (0)
+#else
+#define SN_SYNC() __syncthreads()
+#define SN_WT_FLUSH() do {} while (0)
+#endif
+
 using namespace v3c;
 constexpr int kMaxWaves = 8;
 
@@ -160,6 +180,14 @@ struct PoolIO {
         q.b = __builtin_amdgcn_raw_buffer_load_b128(rin, va, soff + 16, 0);
         return q;
     }
+    // kPacked: va already holds the fetching lane's buffer (b * buf_stride) and the slot of the lane it fetches for
+    __device__ __forceinline__ RawPair issue_packed(int row, int va) const
+    {
+        RawPair q;
+        q.a = __builtin_amdgcn_raw_buffer_load_b128(rin, va, row * row_stride, 0);
+        q.b = __builtin_amdgcn_raw_buffer_load_b128(rin, va, row * row_stride + 16, 0);
+        return q;
+    }
     __device__ __forceinline__ void finish(const RawPair& q, float (&P)[PXL]) const
     {
         P[0] = flt(q.a.x); P[1] = flt(q.a.y); P[2] = flt(q.a.z); P[3] = flt(q.a.w);
@@ -179,7 +207,8 @@ struct PoolIO {
 struct RowCtx {
     int r;
     int vin;       // chroma modes: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
-    int vin_next;  // ... and of row r + 2
+    int vin_next;  // ... and of row r + 2 (kPacked: of the packed fetch)
+    int packed_from;  // kPacked: 4 * (first lane that fetched for this lane)
     int vout;      // voffset of this row's stores (out of range: not kept)
     bool any_out;  // wave-uniform: some lane of this wave stores in this row
 };
@@ -194,13 +223,43 @@ __host__ __device__ constexpr int visit(int i)
 // kPadded: a plane narrower than its pool stride on a zero-filled pool (sn_config.fresh_pool): costs are zero in the padding
 // columns -- a multiplication by 1 or 0 (costs are finite and not negative, so that is exact).  Chroma modes: outside the
 // chroma region the cost of the next row is what the previous pass left there (`stale`, fetched one buffer ahead).
-template <int I, bool S1, int MODE>
+// How a wave of the region gets the previous pass's values in a row of a chroma mode (a wave runs whole loops of one kind):
+//   kQuiet   no lane takes one (a wave inside the region: three of the four of a 4:2:0 pass): no fetch -- even one whose every
+//            lane is out of range is a trip to the texture unit the step would wait for -- and no select;
+//   kPacked  only the last lanes of the wave do (the wave the region ends in: two real lanes and the two ghosts).  A fetch per
+//            buffer and step, one step ahead, is all the registers allow and less than the trip to memory, and the other region
+//            waves wait for this one at every seam barrier.  Instead lane 9 g + b fetches buffer b of the g-th such lane, ONE
+//            fetch for the whole row, issued in the last step of the row before; a step moves its buffer's eight values to
+//            the lanes they belong to with ds_bpermute_b32 (no LDS access);
+//   kFetch   any lane may (rows below the region, planes whose region ends inside a wave's real lanes): a fetch per buffer.
+enum Fetch { kQuiet = 0, kFetch = 1, kPacked = 2 };
+constexpr int kMaxPackedLanes = 7;  // 7 x 9 buffers <= 64 lanes
+
+template <int I, bool S1, int MODE, int FETCH>
 __device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL], unsigned (&rank)[PXL], const Line& n,
                                             const Line& nn, const LaneRole& role, const PoolIO& io, const RowCtx& rc, PoolIO::RawPair& stale)
 {
     constexpr int BUF = visit(I);
     float D[PXL], S[PXL], Bx[PXL], O[PXL];
-    if constexpr (chroma_mode(MODE)) {
+    if constexpr (chroma_mode(MODE) && FETCH == kQuiet) {
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) D[j] = S1 ? cost<BUF>(n, nn, j) : 0.0f;
+    } else if constexpr (chroma_mode(MODE) && FETCH == kPacked) {
+        __builtin_amdgcn_sched_barrier(0);  // one step's moves at a time: hoisted over earlier steps they spill
+        const int from = rc.packed_from + 4 * BUF;  // byte address of the lane that fetched this buffer for this lane
+        D[0] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.x)); D[1] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.y));
+        D[2] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.z)); D[3] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.w));
+        D[4] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.x)); D[5] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.y));
+        D[6] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.z)); D[7] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.w));
+        if constexpr (I + 1 == kBuffers) {
+            __builtin_amdgcn_sched_barrier(0);  // the next row's fetch goes into the registers this row's values have just left
+            stale = io.issue_packed(rc.r + 2, rc.vin_next);
+        }
+        if constexpr (S1) {
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) D[j] = role.inside_b ? cost<BUF>(n, nn, j) : D[j];
+        }
+    } else if constexpr (chroma_mode(MODE)) {
         io.finish(stale, D);
         __builtin_amdgcn_sched_barrier(0);  // the next fetch goes into the registers this one has just left
         if constexpr (I + 1 < kBuffers) stale = io.issue(visit(I + 1), rc.r + 1, rc.vin);
@@ -228,7 +287,7 @@ __device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL],
     if constexpr (MODE == kLumaSpill) {
         if (rc.any_out) io.store(BUF, rc.r, rc.vout, O);  // packed only where a lane of the wave stores
     } else if constexpr (MODE == kChroma) {
-        io.store(BUF, rc.r, rc.vout, O);
+        if (FETCH != kQuiet || rc.any_out) io.store(BUF, rc.r, rc.vout, O);
     }
 }
 
@@ -254,8 +313,10 @@ __device__ __forceinline__ void stale_buffer_step(float (&A)[PXL], const PoolIO:
 
 // buffers 0 .. reg_buffers-1 keep A in VGPRs, the others in LDS between their steps (no scratch spills).  Built without the
 // SLP vectoriser the plain sweep needs ~212 VGPRs with two: six fit without scratch, seven touch the 256 limit; the
-// pool-coupled modes carry the stale row in flight and the row to store, so they keep fewer.
-__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kPadded ? 4 : 6; }
+// pool-coupled modes carry the stale row in flight and the row to store, so they keep fewer.  Five in the chroma modes since
+// round 4: the kPacked rows hold the row's packed fetch AND a step's eight values (six: 44 - 64 bytes of scratch per lane and
+// a V pass 8 % slower instead of 9 % faster; what is left, 16 bytes in kChromaLast, sits in the two rows of kFetch).
+__host__ __device__ constexpr int reg_buffers(int mode) { return mode == kPadded ? 4 : chroma_mode(mode) ? 5 : 6; }
 
 template <int NT, int kRegBuffers>
 struct Parked {
@@ -295,7 +356,7 @@ struct Out {
 };
 
 // S3: the row has an interpolated line (stage 3); a chroma sweep covers rows below its plane without one.
-template <bool S1, bool S3, int MODE, int NT>
+template <bool S1, bool S3, int MODE, int FETCH, int NT>
 __device__ __forceinline__ Out row_step(float (&A)[reg_buffers(MODE)][PXL], const Parked<NT, reg_buffers(MODE)>& pk, int tid, const Line& n,
                                         const Line& nn, const LaneRole& role, float aaf, const PoolIO& io, const RowCtx& rc, PoolIO::RawPair& stale)
 {
@@ -312,11 +373,11 @@ __device__ __forceinline__ Out row_step(float (&A)[reg_buffers(MODE)][PXL], cons
         constexpr int I = decltype(idx)::value;
         constexpr int B = visit(I);
         if constexpr (B < kRegBuffers) {
-            buffer_step<I, S1, MODE>(A[B], vmin, rank, n, nn, role, io, rc, stale);
+            buffer_step<I, S1, MODE, FETCH>(A[B], vmin, rank, n, nn, role, io, rc, stale);
         } else {
             float t[PXL];
             pk.load_A(tid, B, t);
-            buffer_step<I, S1, MODE>(t, vmin, rank, n, nn, role, io, rc, stale);
+            buffer_step<I, S1, MODE, FETCH>(t, vmin, rank, n, nn, role, io, rc, stale);
             pk.store_A(tid, B, t);
         }
     };
@@ -394,6 +455,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     mb.h = reinterpret_cast<unsigned*>(parked.a + (kBuffers - kRegBuffers) * 2 * NT);
     const int wave = tid >> 6;
     const int lane = tid & 63;
+#ifdef SN_WAVE_TIMING
+    const unsigned long long wt_start = __builtin_amdgcn_s_memtime();
+    unsigned long long wt_barrier = 0;
+#endif
 
     int gl;
     bool ghost;
@@ -466,12 +531,12 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         io.v_out = real ? (linear ? x0 * 4 : tid * 32) : kOutOfRange;
     }
     // Does this lane's slot of pool row q matter (Args::cone_*)?  Its first column is 8 * lane + 480 * wave.
-    auto in_cone = [&](int q, int extra) -> bool {
+    auto in_cone_at = [&](int q, int extra, int xa) -> bool {
         const int lim = a.cone_w + 3 * (a.cone_nr - q + 2) + extra;
         const int cols = lim < a.w ? lim : a.w;
-        const int xa = (lane << 3) + wave * (kInner * PXL);
         return xa < cols && (q > a.cone_nr || xa + PXL > a.cone_w);
     };
+    auto in_cone = [&](int q, int extra) -> bool { return in_cone_at(q, extra, (lane << 3) + wave * (kInner * PXL)); };
 
     // seam exchange: lanes 60, 61 feed the next wave's left ghosts, lanes 2, 3 the previous wave's right ghosts
     const bool pub_right = lane >= 64 - 2 * GH && lane < 64 - GH && wave < NW - 1;
@@ -513,13 +578,16 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
             }
             for (int r = 1; r <= sweep; ++r) {
 #ifdef SN_X_BALANCED  // DIAGNOSTIC (wrong results): every stale wave lives 5/9 of the sweep, the load of a balanced hand-over
-                if (r > sweep * 5 / 9) return;
+                if (r > sweep * 5 / 9) { SN_WT_FLUSH(); return; }
 #else
-                if (x_wave >= a.cone_w + 3 * (a.cone_nr - (r - 1) + 2) + a.cone_in) return;  // outside for good
+                if (x_wave >= a.cone_w + 3 * (a.cone_nr - (r - 1) + 2) + a.cone_in) {  // outside for good
+                    SN_WT_FLUSH();
+                    return;
+                }
 #endif
                 const int vin = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
                 if (r > 1 && (r - 1) % K == 0) {
-                    __syncthreads();
+                    SN_SYNC();
                     if (recv) {
                         const unsigned* from = mb.at((r / K) & 1, wave, lane < GH ? 0 : 1, slot);
 #pragma unroll
@@ -555,6 +623,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
                     }
                 }
             }
+            SN_WT_FLUSH();
             return;
         }
     }
@@ -610,10 +679,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     src_next += src_step;
 
     PoolIO::RawPair stale_next{};
-    if constexpr (chroma_mode(MODE)) stale_next = io.issue(visit(0), r0 + 1, (r0 + 1 <= a.rows_in && in_cone(r0 + 1, a.cone_in)) ? io.v_a : kOutOfRange);
+    int packed_x = 0, packed_va = kOutOfRange, packed_from = 0;  // kPacked (set before its loop)
     TurnTaking turns;
     turns.init(a.turn_shift);
-    auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag) {
+    // fetch_tag (chroma modes): false for the rows in which no lane of this wave takes a stale value (buffer_step)
+    auto step = [&](int r, Line& n, Line& nn, auto s1_tag, auto s3_tag, auto fetch_tag) {
         constexpr bool S1 = decltype(s1_tag)::value;
         constexpr bool S3 = decltype(s3_tag)::value;
         turns.update((r - 1) % K);
@@ -629,7 +699,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         }
         const int par = (r / K) & 1;
         if (r > r0 && (r - 1) % K == 0) {
-            __syncthreads();
+            SN_SYNC();
             if (recv) {
                 const unsigned* from = mb.at(par, wave, lane < GH ? 0 : 1, slot);
 #pragma unroll
@@ -650,7 +720,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         rc.vin = rc.vout = kOutOfRange;
         rc.any_out = false;
         rc.vin_next = kOutOfRange;
-        if constexpr (chroma_mode(MODE)) rc.vin_next = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
+        rc.packed_from = packed_from;
+        constexpr int kKind = chroma_mode(MODE) ? decltype(fetch_tag)::value : (int)kQuiet;
+        if constexpr (chroma_mode(MODE) && kKind == kPacked) rc.vin_next = (r + 2 <= a.rows_in && in_cone_at(r + 2, a.cone_in, packed_x)) ? packed_va : kOutOfRange;
+        else if constexpr (chroma_mode(MODE)) rc.vin_next = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
         if constexpr (chroma_mode(MODE)) rc.vin = (r + 1 <= a.rows_in && in_cone(r + 1, a.cone_in)) ? io.v_a : kOutOfRange;
 #ifdef SN_X_REGION_NOSTALE  // DIAGNOSTIC (wrong results): what do the stale loads of the region's ghost lanes cost?
         rc.vin = kOutOfRange;
@@ -659,7 +732,7 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
             rc.vout = (r <= a.rows_out && (!BAND || r >= ra) && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
         }
-        const Out o = row_step<S1, S3, MODE>(A, parked, tid, n, nn, role, aaf, io, rc, stale_next);
+        const Out o = row_step<S1, S3, MODE, kKind>(A, parked, tid, n, nn, role, aaf, io, rc, stale_next);
         if constexpr (S3) put(out_row, o);
         out_row += dst_step;
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c
@@ -703,25 +776,62 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         };
         int r = r0;
         for (; r < ra; ++r) {  // the run-up: nothing interpolated
-            step(r, L1, L0, T{}, F{});
+            step(r, L1, L0, T{}, F{}, T{});
             L1 = L0;
         }
         leave_state(0);
         const int own_next = rb < nr ? rb + 1 : nr;
         for (; r < own_next; ++r) {
-            step(r, L1, L0, T{}, T{});
+            step(r, L1, L0, T{}, T{}, T{});
             L1 = L0;
         }
-        if (rb == nr) step(nr, L1, L0, F{}, T{});
+        if (rb == nr) step(nr, L1, L0, F{}, T{}, T{});
         else leave_state(1);
     } else {
-        for (int r = 1; r < nr; ++r) {
-            step(r, L1, L0, T{}, T{});
+        using Quiet = std::integral_constant<int, kQuiet>;
+        using Packed = std::integral_constant<int, kPacked>;
+        int from = 1;  // rows [1, from) have been swept
+        if constexpr (chroma_mode(MODE)) {
+            // rows 1 .. calm - 1 fetch pool rows 2 .. calm <= cone_nr, where only lanes right of the region take stale values
+            const int calm = nr < a.cone_nr ? nr : a.cone_nr;
+            const int xa = (lane << 3) + wave * (kInner * PXL);
+            const int lim = a.cone_w + 3 * (a.cone_nr - 2 + 2) + a.cone_in;  // in_cone(2, cone_in): the widest of those rows
+            const bool beyond = xa < (lim < a.w ? lim : a.w) && xa + PXL > a.cone_w;
+            const unsigned long long takers = __ballot(beyond);  // wave-uniform
+            // (three loops one after the other, two of them empty: as arms of a branch their register allocations collide)
+            const bool packed = takers != 0 && wave < NW - 1 && (takers >> (64 - kMaxPackedLanes)) << (64 - kMaxPackedLanes) == takers;
+            const int quiet_end = takers == 0 ? calm : 1, packed_end = packed ? calm : 1;
+            for (int r = 1; r < quiet_end; ++r) {
+                step(r, L1, L0, T{}, T{}, Quiet{});
+                L1 = L0;
+            }
+            {
+                // kPacked: the takers are among the wave's last kMaxPackedLanes lanes (the others of those fetch too; the select
+                // drops their values)
+                const int first = 64 - kMaxPackedLanes;
+                const int g = lane / kBuffers, b = lane - g * kBuffers;  // this lane fetches buffer b for lane first + g
+                const int t = first + g;
+                const int owner = t < 64 - GH ? wave * 64 + t : (wave + 1) * 64 + GH + (t - (64 - GH));  // ghosts read their owner's slot
+                packed_x = (t << 3) + wave * (kInner * PXL);
+                packed_va = packed && g < kMaxPackedLanes ? owner * 32 + b * io.buf_stride : kOutOfRange;
+                packed_from = lane >= first ? 4 * kBuffers * (lane - first) : 0;
+                stale_next = io.issue_packed(2, (2 <= a.rows_in && in_cone_at(2, a.cone_in, packed_x)) ? packed_va : kOutOfRange);
+            }
+            for (int r = 1; r < packed_end; ++r) {
+                step(r, L1, L0, T{}, T{}, Packed{});
+                L1 = L0;
+            }
+            from = takers == 0 || packed ? (calm > 1 ? calm : 1) : 1;
+            // the first buffer of the first row that fetches buffer by buffer
+            stale_next = io.issue(visit(0), from + 1, (from + 1 <= a.rows_in && in_cone(from + 1, a.cone_in)) ? io.v_a : kOutOfRange);
+        }
+        for (int r = from; r < nr; ++r) {
+            step(r, L1, L0, T{}, T{}, T{});
             L1 = L0;
         }
-        if (nr >= 1) step(nr, L1, L0, F{}, T{});
+        if (nr >= 1) step(nr, L1, L0, F{}, T{}, T{});
         if constexpr (chroma_mode(MODE)) {
-            for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{});
+            for (int r = nr + 1; r <= sweep; ++r) step(r, L1, L0, F{}, F{}, T{});
         }
     }
 
@@ -730,7 +840,25 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         const Raw q = load_raw(src_line + (nk - 1) * src_step);
         keep((2 * nk - 1) * a.dst_pitch, q);
     }
+    SN_WT_FLUSH();
 }
+
+#ifdef SN_WAVE_TIMING
+}  // namespace f32
+}  // namespace sn
+extern "C" __attribute__((visibility("default"))) int sn_debug_wave_ticks_f32(unsigned long long out[5 * 8 * 2], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sn::f32::sn_wave_ticks), 5 * 8 * 2 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        static const unsigned long long zero[5 * 8 * 2] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sn::f32::sn_wave_ticks), zero, sizeof zero) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace sn {
+namespace f32 {
+#endif
 
 template <int MODE, bool BAND = false>
 static hipError_t launch_mode(hipStream_t st, const Args& a, float aaf, int nframes)

@@ -711,7 +711,11 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
             };
             fetch(2, sa);
             auto stale_row = [&](int r, const u32x4 (&cur)[kBuffers], u32x4 (&nxt)[kBuffers]) -> bool {
+#ifdef SN_X_BALANCED  // DIAGNOSTIC (wrong results): every stale wave lives 5/9 of the sweep, the load of a balanced hand-over
+                if (r > sweep * 5 / 9) return false;
+#else
                 if (x_wave >= a.cone_w + 3 * (a.cone_nr - (r - 1) + 2) + a.cone_in) return false;  // outside for good
+#endif
                 fetch(r + 2, nxt);
                 if (r > 1 && (r - 1) % K == 0) {
                     SN_SYNC();
