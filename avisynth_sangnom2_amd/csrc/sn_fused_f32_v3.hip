@@ -208,7 +208,9 @@ struct RowCtx {
     int r;
     int vin;       // chroma modes: voffset of the loads of row r + 1 (out of range: row missing or outside the cone)
     int vin_next;  // ... and of row r + 2 (kPacked: of the packed fetch)
-    int packed_from;  // kPacked: 4 * (first lane that fetched for this lane)
+    const uint4* packed_lds;  // kPacked: where the lane that fetched buffer 0 for this lane left the first half of its values
+    int packed_half;          // ... and how many uint4 further the second half
+    uint4* packed_out;        // kPacked, kChroma: where this lane leaves buffer 0's O for the row's one store (null: hands nothing on)
     int vout;      // voffset of this row's stores (out of range: not kept)
     bool any_out;  // wave-uniform: some lane of this wave stores in this row
 };
@@ -229,8 +231,10 @@ __host__ __device__ constexpr int visit(int i)
 //   kPacked  only the last lanes of the wave do (the wave the region ends in: two real lanes and the two ghosts).  A fetch per
 //            buffer and step, one step ahead, is all the registers allow and less than the trip to memory, and the other region
 //            waves wait for this one at every seam barrier.  Instead lane 9 g + b fetches buffer b of the g-th such lane, ONE
-//            fetch for the whole row, issued in the last step of the row before; a step moves its buffer's eight values to
-//            the lanes they belong to with ds_bpermute_b32 (no LDS access);
+//            fetch for the whole row, issued a row ahead; when a row begins the fetched values go to LDS (the parking slots of
+//            the workgroup's last wave, which lies right of the region and parks nothing) and the fetch of the row after next
+//            starts BEFORE this row's stores -- a wait for it later waits for nothing younger; a step reads its buffer's eight
+//            values as two ds_read_b128;
 //   kFetch   any lane may (rows below the region, planes whose region ends inside a wave's real lanes): a fetch per buffer.
 enum Fetch { kQuiet = 0, kFetch = 1, kPacked = 2 };
 constexpr int kMaxPackedLanes = 7;  // 7 x 9 buffers <= 64 lanes
@@ -245,16 +249,10 @@ __device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL],
 #pragma unroll
         for (int j = 0; j < PXL; ++j) D[j] = S1 ? cost<BUF>(n, nn, j) : 0.0f;
     } else if constexpr (chroma_mode(MODE) && FETCH == kPacked) {
-        __builtin_amdgcn_sched_barrier(0);  // one step's moves at a time: hoisted over earlier steps they spill
-        const int from = rc.packed_from + 4 * BUF;  // byte address of the lane that fetched this buffer for this lane
-        D[0] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.x)); D[1] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.y));
-        D[2] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.z)); D[3] = flt(__builtin_amdgcn_ds_bpermute(from, stale.a.w));
-        D[4] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.x)); D[5] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.y));
-        D[6] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.z)); D[7] = flt(__builtin_amdgcn_ds_bpermute(from, stale.b.w));
-        if constexpr (I + 1 == kBuffers) {
-            __builtin_amdgcn_sched_barrier(0);  // the next row's fetch goes into the registers this row's values have just left
-            stale = io.issue_packed(rc.r + 2, rc.vin_next);
-        }
+        __builtin_amdgcn_sched_barrier(0);  // one step's reads at a time: hoisted over earlier steps they spill
+        const uint4 lo = rc.packed_lds[BUF], hi = rc.packed_lds[rc.packed_half + BUF];
+        D[0] = flt(lo.x); D[1] = flt(lo.y); D[2] = flt(lo.z); D[3] = flt(lo.w);
+        D[4] = flt(hi.x); D[5] = flt(hi.y); D[6] = flt(hi.z); D[7] = flt(hi.w);
         if constexpr (S1) {
 #pragma unroll
             for (int j = 0; j < PXL; ++j) D[j] = role.inside_b ? cost<BUF>(n, nn, j) : D[j];
@@ -287,7 +285,16 @@ __device__ __forceinline__ void buffer_step(float (&A)[PXL], float (&vmin)[PXL],
     if constexpr (MODE == kLumaSpill) {
         if (rc.any_out) io.store(BUF, rc.r, rc.vout, O);  // packed only where a lane of the wave stores
     } else if constexpr (MODE == kChroma) {
-        if (FETCH != kQuiet || rc.any_out) io.store(BUF, rc.r, rc.vout, O);
+        if constexpr (FETCH == kPacked) {
+            // the few lanes that hand a value on leave it in LDS; the row's end stores all nine buffers' with one store (the
+            // way they were fetched): nine stores of two live lanes each queued behind the stale waves' full ones
+            if (rc.packed_out) {
+                rc.packed_out[BUF] = make_uint4(bits(O[0]), bits(O[1]), bits(O[2]), bits(O[3]));
+                rc.packed_out[rc.packed_half + BUF] = make_uint4(bits(O[4]), bits(O[5]), bits(O[6]), bits(O[7]));
+            }
+        } else {
+            if (FETCH != kQuiet || rc.any_out) io.store(BUF, rc.r, rc.vout, O);
+        }
     }
 }
 
@@ -679,7 +686,10 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
     src_next += src_step;
 
     PoolIO::RawPair stale_next{};
-    int packed_x = 0, packed_va = kOutOfRange, packed_from = 0;  // kPacked (set before its loop)
+    int packed_x = 0, packed_va = kOutOfRange;  // kPacked (set before its loop)
+    const uint4* packed_lds = parked.v;
+    uint4* packed_out = nullptr;
+    int packed_vout = kOutOfRange;
     TurnTaking turns;
     turns.init(a.turn_shift);
     // fetch_tag (chroma modes): false for the rows in which no lane of this wave takes a stale value (buffer_step)
@@ -720,7 +730,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
         rc.vin = rc.vout = kOutOfRange;
         rc.any_out = false;
         rc.vin_next = kOutOfRange;
-        rc.packed_from = packed_from;
+        rc.packed_lds = packed_lds;
+        rc.packed_half = NT;
+        rc.packed_out = packed_out;
         constexpr int kKind = chroma_mode(MODE) ? decltype(fetch_tag)::value : (int)kQuiet;
         if constexpr (chroma_mode(MODE) && kKind == kPacked) rc.vin_next = (r + 2 <= a.rows_in && in_cone_at(r + 2, a.cone_in, packed_x)) ? packed_va : kOutOfRange;
         else if constexpr (chroma_mode(MODE)) rc.vin_next = (r + 2 <= a.rows_in && in_cone(r + 2, a.cone_in)) ? io.v_a : kOutOfRange;
@@ -732,7 +744,22 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
             rc.vout = (r <= a.rows_out && (!BAND || r >= ra) && in_cone(r, a.cone_out)) ? io.v_out : kOutOfRange;
             rc.any_out = __builtin_amdgcn_readfirstlane(__any(rc.vout != kOutOfRange) ? 1 : 0) != 0;
         }
+        if constexpr (kKind == kPacked) {  // this row's values to LDS, the next row's fetch on its way
+            parked.v[(NW - 1) * 64 + lane] = make_uint4(stale_next.a.x, stale_next.a.y, stale_next.a.z, stale_next.a.w);
+            parked.v[NT + (NW - 1) * 64 + lane] = make_uint4(stale_next.b.x, stale_next.b.y, stale_next.b.z, stale_next.b.w);
+            __builtin_amdgcn_sched_barrier(0);
+            stale_next = io.issue_packed(r + 2, rc.vin_next);
+        }
         const Out o = row_step<S1, S3, MODE, kKind>(A, parked, tid, n, nn, role, aaf, io, rc, stale_next);
+        if constexpr (kKind == kPacked && MODE == kChroma) {  // the row's one store: lane 9 g + b stores buffer b of lane first + g
+            const uint4 lo = parked.v[2 * NT + (NW - 1) * 64 + lane], hi = parked.v[3 * NT + (NW - 1) * 64 + lane];
+            const int vo = (r <= a.rows_out && in_cone_at(r, a.cone_out, packed_x)) ? packed_vout : kOutOfRange;
+            u32x4 d0, d1;
+            d0.x = lo.x; d0.y = lo.y; d0.z = lo.z; d0.w = lo.w;
+            d1.x = hi.x; d1.y = hi.y; d1.z = hi.z; d1.w = hi.w;
+            store_b128(d0, io.rout, vo, r * io.row_stride);
+            store_b128(d1, io.rout, vo, r * io.row_stride + 16);
+        }
         if constexpr (S3) put(out_row, o);
         out_row += dst_step;
         if constexpr (S1) parked.park(tid, n);  // n is the next row's c
@@ -814,7 +841,9 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_f32_v3(Args
                 const int owner = t < 64 - GH ? wave * 64 + t : (wave + 1) * 64 + GH + (t - (64 - GH));  // ghosts read their owner's slot
                 packed_x = (t << 3) + wave * (kInner * PXL);
                 packed_va = packed && g < kMaxPackedLanes ? owner * 32 + b * io.buf_stride : kOutOfRange;
-                packed_from = lane >= first ? 4 * kBuffers * (lane - first) : 0;
+                packed_lds = parked.v + (NW - 1) * 64 + (lane >= first ? kBuffers * (lane - first) : 0);
+                packed_out = lane >= first ? parked.v + 2 * NT + (NW - 1) * 64 + kBuffers * (lane - first) : nullptr;
+                packed_vout = packed && g < kMaxPackedLanes && t < 64 - GH ? (wave * 64 + t) * 32 + b * io.buf_stride : kOutOfRange;  // ghosts store nothing
                 stale_next = io.issue_packed(2, (2 <= a.rows_in && in_cone_at(2, a.cone_in, packed_x)) ? packed_va : kOutOfRange);
             }
             for (int r = 1; r < packed_end; ++r) {
