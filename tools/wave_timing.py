@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Which wave of a coupled 16-bit / float sweep does the workgroup wait for?  Per mode (1 luma with hand-off, 2 U, 4 V) and wave
 index: shader-clock ticks between a wave's start and its end, and the part of them spent at the seam barriers (a library whose
-sn_fused_u16_v3.o and sn_fused_f32_v3.o were built with -DSN_WAVE_TIMING):
+sn_fused_u16_v3.o and sn_fused_f32_v3.o were built with -DSN_WAVE_TIMING:
+`make -C avisynth_sangnom2_amd/csrc EXTRA=-DSN_WAVE_TIMING -B sn_fused_u16_v3.o sn_fused_f32_v3.o && make -C avisynth_sangnom2_amd/csrc`,
+keep the result as ab/wave_timing.so and rebuild the two objects without the flag):
     SN_LIB=ab/wave_timing.so python3 tools/wave_timing.py [frames = 256]"""
 import ctypes
 import os
