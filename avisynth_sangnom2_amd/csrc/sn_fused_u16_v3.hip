@@ -958,7 +958,13 @@ __global__ void __launch_bounds__(NW * group_of(NW) * 64, 2) k_fused_u16_v3(Args
         if constexpr (MODE == kLumaSpill) {
             // the rows a chroma pass can see first, with the hand-off; the rest of the plane without
             const int split = a.rows_out + 1 < nr ? a.rows_out + 1 : nr;
-            rows(1, split, T{}, T{});
+            // a wave left of the cone hands nothing on in the rows of the chroma region (only in the row or two below it, which
+            // the next pass reads whole): it runs those rows without the packing and the stores, whose issue slots its SIMD
+            // partner -- a wave of the right half, the ones the workgroup waits for -- can use
+            const bool hands_on = __builtin_amdgcn_readfirstlane(__any(real && in_cone(1, a.cone_out)) ? 1 : 0) != 0;
+            const int idle = hands_on ? 1 : (a.cone_nr + 1 < split ? a.cone_nr + 1 : split);
+            rows(1, idle, F{}, T{});
+            rows(idle, split, T{}, T{});
             rows(split, nr, F{}, T{});
             if (nr >= 1) {
                 step(nr, L1, L0, F{}, T{}, T{}, T{});
