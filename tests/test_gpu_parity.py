@@ -1450,11 +1450,14 @@ def test_launches_of_hundreds_of_small_frames_stay_on_the_whole_plane_sweeps(hip
 
 
 @pytest.mark.parametrize("fmt", ["YUV420P8", "YUV422P8", "YUV420P16", "YUV420PS"])
-@pytest.mark.parametrize("w,h", [(512, 400), (992, 720), (1472, 1000), (544, 400), (1024, 720)])
+@pytest.mark.parametrize("w,h", [(512, 400), (992, 720), (1472, 1000), (544, 400), (1024, 720), (960, 400), (1920, 300), (2912, 200)])
 def test_coupled_sweeps_equal_the_pool_path_where_the_cone_reaches_the_last_columns(hip_lib, fmt, w, h):
     """Tall frames of widths whose last strip ends on lanes 62 / 63 (64 + 60 k lanes: 512, 992, 1472) and of their
     neighbours: the hand-off's dependency cone then includes the last columns of the pool, which short test frames
-    never reach (the 8-bit sweeps once read zeros there).  Whole-plane sweeps against the pool path, byte for byte."""
+    never reach (the 8-bit sweeps once read zeros there).  Whole-plane sweeps against the pool path, byte for byte.
+    960, 1920 (and 3840, in the full-size tests): the chroma region ends two real lanes before a wave's ghosts -- the 16-bit
+    sweep's fetch ring and the float sweep's packed fetch / packed store (kPacked) with the other region waves in their loops
+    without a fetch; 992: only the ghosts take stale values; 512, 1472, 2912: the region ends in the middle of a wave (kFetch)."""
     hh = h if fmt != "YUV422P8" else h // 2
     clip = clip_format(fmt, w, hh)
     kw = dict(aa=128, aac=128)
