@@ -50,6 +50,11 @@ WORKLOADS = {
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
     "2160p-Y32": ("Y32", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420PS": ("YUV420PS", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    # DCI 4K: wider than eight strips of 480 columns -- 8-bit planes still sweep (two strips per wave), 8-bit 4:2:0 chroma in the
+    # two-sweep form, 16-bit planes on the pool path
+    "dci4k-Y8": ("Y8", 4096, 2160, dict(order=1, aa=48)),
+    "dci4k-YUV420P8": ("YUV420P8", 4096, 2160, dict(order=1, aa=48, aac=48)),
+    "dci4k-Y16": ("Y16", 4096, 2160, dict(order=1, aa=48)),
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
@@ -339,7 +344,7 @@ def main():
     strips = 1 if sweep_w <= 512 else 1 + -(-(sweep_w // 8 - 62) // 60)
     waves_per_frame = strips if clip.bytes >= 2 else (strips + 1) // 2
     out_bytes = frame_in_bytes * (2 if kw.get("dh") else 1)
-    per_round = 256 * (8 // waves_per_frame)        # workgroups resident at a time
+    per_round = 256 * max(1, 8 // waves_per_frame)  # workgroups resident at a time (planes too wide for the sweeps: as for eight waves)
     fit = (48 << 30) // (frame_in_bytes + out_bytes)
     if clip.planes >= 3 and clip.subw + clip.subh > 0 and not (kw.get("isolated_planes") or kw.get("fresh_pool")):
         # the 4:2:0 sweeps also need hand-off pools per frame: two, or one where U and V run as one sweep (8-bit up to 3840 columns)
