@@ -50,6 +50,9 @@ WORKLOADS = {
     "2160p-YUV444PS-dh": ("YUV444PS", 3840, 1080, dict(order=1, aa=48, aac=48, dh=True)),
     "2160p-Y32": ("Y32", 3840, 2160, dict(order=1, aa=48)),
     "2160p-YUV420PS": ("YUV420PS", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "2160p-YUV422P16": ("YUV422P16", 3840, 2160, dict(order=1, aa=48, aac=48)),
+    "1080p-YUV420P16": ("YUV420P16", 1920, 1080, dict(order=1, aa=48, aac=48)),
+    "1080p-YUV420PS": ("YUV420PS", 1920, 1080, dict(order=1, aa=48, aac=48)),
     # DCI 4K: wider than eight strips of 480 columns -- 8-bit planes still sweep (two strips per wave), 8-bit 4:2:0 chroma in the
     # two-sweep form, 16-bit planes on the pool path
     "dci4k-Y8": ("Y8", 4096, 2160, dict(order=1, aa=48)),
